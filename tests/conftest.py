@@ -1,0 +1,26 @@
+"""pytest configuration: markers and import paths.
+
+`-m "not gpu"` runs on the CPU-only build container; `-m gpu` runs on a real MI355X and
+goes through the C ABI (libs2sr.so).  /root/reference is never read from tests.
+"""
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / "sentinel2-super-resolution-poc_amd"
+for p in (str(PKG), str(REPO)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = REPO / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
