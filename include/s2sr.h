@@ -1,0 +1,143 @@
+/*
+ * s2sr.h -- C ABI of libs2sr.so, the MI355X (gfx950) Real-ESRGAN x4 inference path.
+ *
+ * The reference (fieldin/sentinel2-super-resolution-poc) has no FFI layer: its seam is the
+ * Python class `RealESRGAN` (server/app/cnn_super_resolution.py:161-280) plus the free
+ * functions `_enhance_for_crops` (server/app/wow_sr.py:187-209) and the farm variants
+ * (server/app/farm_sr.py:61-108).  This header is the native boundary a replacement of that
+ * seam binds; the ctypes stub that sits on it is in INTEGRATION.md and
+ * in sentinel2-super-resolution-poc_amd/s2sr/native.py.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a negative
+ * S2SR_E_* code; no exception crosses the boundary; outputs are caller-allocated; the last
+ * error text is handle-scoped (s2sr_last_error).  A handle serialises its own calls
+ * (internal mutex), so it may be shared by the reference's worker threads
+ * (server/app/main.py:247-368 run jobs from a thread pool).
+ *
+ * Pointers named `d_*` are DEVICE pointers (HIP), everything else is host memory.
+ */
+#ifndef S2SR_H
+#define S2SR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2SR_OK            0
+#define S2SR_E_INVALID    -1   /* bad argument */
+#define S2SR_E_HIP        -2   /* HIP runtime error (text in s2sr_last_error) */
+#define S2SR_E_NOWEIGHTS  -3   /* forward called before s2sr_load_weights */
+#define S2SR_E_BADBLOB    -4   /* weight blob size does not match the configured net */
+#define S2SR_E_NODEVICE   -5   /* no gfx950 device visible: there is NO CPU fallback */
+#define S2SR_E_CAPACITY   -6   /* caller buffer too small */
+
+/* arithmetic of the conv stack */
+#define S2SR_PREC_F16  0   /* fp16 operands, fp32 accumulate on MFMA; fp32 residual trunk  */
+#define S2SR_PREC_F32  1   /* exact fp32 (fp32 MFMA), the parity mode                       */
+
+typedef struct s2sr_handle s2sr_handle;
+
+/* Mirrors the constructor arguments of the reference net
+ * `RRDBNet(num_in_ch=3,num_out_ch=3,num_feat,num_block,num_grow_ch=32,scale)`
+ * (cnn_super_resolution.py:113-121,196-203) plus device-side knobs. */
+typedef struct s2sr_config {
+    int32_t num_block;   /* 23 (realesrgan_x4) or 6 (realesrgan_anime), cnn_super_resolution.py:28-45 */
+    int32_t num_feat;    /* must be 64 */
+    int32_t num_grow;    /* must be 32 */
+    int32_t scale;       /* must be 4 (the only scale in the reference's MODELS table) */
+    int32_t precision;   /* S2SR_PREC_* */
+    int32_t device;      /* HIP device ordinal */
+    int32_t group;       /* images pushed through the trunk together (0 = default) */
+    int32_t reserved;
+} s2sr_config;
+
+/* One window of RealESRGAN._tile_process (cnn_super_resolution.py:244-278). */
+typedef struct s2sr_window {
+    int32_t y1, y2, x1, x2;             /* input rectangle, LR pixels                          */
+    int32_t crop_top, crop_bottom, crop_left, crop_right;   /* output pixels dropped           */
+    int32_t oy1, oy2, ox1, ox2;         /* paste rectangle in the output image                 */
+} s2sr_window;
+
+/* Constants of the crop-visibility post-process (wow_sr.py:187-209 / farm_sr.py:61-108,170-178). */
+typedef struct s2sr_pp_params {
+    float   clahe_clip;      /* cv2.createCLAHE clipLimit: 2.5                     */
+    int32_t clahe_grid;      /* tileGridSize (g,g): 8                              */
+    float   blur_sigma;      /* GaussianBlur sigma: 1.2 (wow) / 1.5 (farm)         */
+    float   w_img;           /* addWeighted alpha: 1.4 (wow) / 2.2 (farm)          */
+    float   w_blur;          /* addWeighted beta: -0.4 (wow) / -1.2 (farm)         */
+    int32_t hue_lo, hue_hi;  /* exclusive hue bounds of the green mask: 35, 85     */
+    float   sat_gain;        /* 1.2 (wow) / 1.3 (farm)                             */
+    int32_t stages;          /* bit0 CLAHE, bit1 unsharp, bit2 vegetation; 7 = all */
+} s2sr_pp_params;
+
+/* per-kernel-family timing collected with HIP events on the handle's stream */
+typedef struct s2sr_kstat {
+    char     name[48];
+    int64_t  launches;
+    double   total_ms;
+    double   flops;          /* algorithmic FLOP summed over those launches  */
+    double   bytes;          /* algorithmic HBM bytes summed over those launches */
+} s2sr_kstat;
+
+const char* s2sr_version(void);
+int  s2sr_device_count(void);      /* number of HIP devices (0 when there is no GPU) */
+
+/* replaces RealESRGAN.__init__'s model construction (cnn_super_resolution.py:196-203) */
+int  s2sr_create(const s2sr_config* cfg, s2sr_handle** out);
+void s2sr_destroy(s2sr_handle* h);
+const char* s2sr_last_error(const s2sr_handle* h);   /* h may be NULL: last create() error */
+
+/* replaces load_state_dict (cnn_super_resolution.py:205-213).  `blob`: for every conv in
+ * registration order (conv_first, body.{b}.rdb{1..3}.conv{1..5}, conv_body, conv_up1,
+ * conv_up2, conv_hr, conv_last): weight[Cout][Cin][3][3] then bias[Cout], fp32. */
+int  s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats);
+size_t s2sr_expected_blob_floats(int32_t num_block);
+
+/* pure host function = the index math of _tile_process (cnn_super_resolution.py:244-278) */
+int  s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t scale,
+                     s2sr_window* out, int32_t cap, int32_t* n);
+
+/* replaces RRDBNet.forward + the u8 quantisation of enhance() on a batch of equal-size tiles
+ * (cnn_super_resolution.py:140-158,220-222,231-232): [B,h,w,3] u8 -> [B,4h,4w,3] u8. */
+int  s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw,
+                           uint8_t* out);
+/* same with device-resident input/output; `stream` is a hipStream_t or NULL (= handle stream) */
+int  s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, int32_t th, int32_t tw,
+                               void* d_out, void* stream);
+/* unquantised net output for parity tests: x [N,3,H,W] fp32 in [0,1] -> y [N,3,4H,4W] fp32 */
+int  s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32_t W, float* y);
+
+/* replaces RealESRGAN.enhance incl. the whole/tiled switch and _tile_process
+ * (cnn_super_resolution.py:217-280): HxWx3 u8 -> 4Hx4Wx3 u8, channel order as given. */
+int  s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
+                     int32_t tile, int32_t pad, uint8_t* out);
+/* float image before quantisation (HWC fp32), for parity tests of the tiled path */
+int  s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
+                      int32_t tile, int32_t pad, float* out);
+
+/* replaces _enhance_for_crops (wow_sr.py:187-209) and enhance_local_contrast /
+ * apply_unsharp_mask / enhance_vegetation (farm_sr.py:61-108): HxWx3 u8 RGB -> same. */
+int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W,
+                         const s2sr_pp_params* prm, uint8_t* out);
+int  s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
+                                   const s2sr_pp_params* prm, void* d_out, void* stream);
+
+/* measurement: HIP-event timing per kernel family on the launch stream */
+int  s2sr_set_profiling(s2sr_handle* h, int32_t on);
+int  s2sr_get_kernel_stats(s2sr_handle* h, s2sr_kstat* out, int32_t cap, int32_t* n);
+int  s2sr_reset_kernel_stats(s2sr_handle* h);
+int  s2sr_synchronize(s2sr_handle* h);
+
+/* test hook: one 3x3 conv layer on NCHW fp32 host tensors through the production kernel
+ * (upsample != 0 -> nearest-2x on load).  act: 0 none, 1 LeakyReLU(0.2). */
+int  s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                     const float* weight, const float* bias, int32_t Cout, int32_t upsample,
+                     int32_t act, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2SR_H */

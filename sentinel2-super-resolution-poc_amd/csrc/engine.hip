@@ -1,0 +1,696 @@
+// libs2sr engine: handle, weights, workspace planes and the layer schedule of
+// RRDBNet.forward / RealESRGAN.enhance (reference server/app/cnn_super_resolution.py:140-158,
+// 217-280) on top of the conv kernel in conv_mfma.hip.  This file is the C ABI of
+// include/s2sr.h.  There is no CPU fallback anywhere in this library.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "s2sr_internal.h"
+
+using namespace s2sr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ConvW {
+    int cin = 0, cout = 0, nchunks = 0, ct = 0;
+    void* d_wpack = nullptr;
+    float* d_bias = nullptr;
+};
+
+// kernel families for the HIP-event statistics
+enum Fam { F_PACK, F_FIRST, F_RDB14, F_RDB5, F_BODY, F_UP, F_HR, F_LAST, F_POST, F_MISC, F_COUNT };
+const char* kFamName[F_COUNT] = {"pack_u8",   "conv_first", "rdb_conv1-4", "rdb_conv5",   "conv_body",
+                                 "conv_up",   "conv_hr",    "conv_last",   "postprocess", "misc"};
+
+struct Workspace {
+    int G = 0, H = 0, W = 0;   // capacity (images) and logical LR dims
+    char* base = nullptr;
+    size_t bytes = 0;
+    // LR planes
+    char *P0 = nullptr, *X[2] = {nullptr, nullptr}, *Gd = nullptr, *U0 = nullptr;
+    float *T = nullptr, *R = nullptr, *F = nullptr;
+    // 2x and 4x planes
+    char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
+    int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
+};
+
+struct EvRec {
+    int fam;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct s2sr_handle {
+    s2sr_config cfg{};
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    std::vector<ConvW> convs;
+    bool has_weights = false;
+    Workspace ws;
+    // scratch device buffers (grown on demand)
+    void* d_scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    // profiling
+    bool prof = false;
+    std::vector<EvRec> evs;
+    std::vector<hipEvent_t> ev_pool;
+    s2sr_kstat stats[F_COUNT];
+};
+
+namespace {
+
+int fail(s2sr_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            char b__[512];                                                                     \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return fail(h, S2SR_E_HIP, b__);                                                   \
+        }                                                                                      \
+    } while (0)
+
+struct ConvSpec {
+    int cin, cout;
+};
+
+std::vector<ConvSpec> conv_specs(int num_block) {
+    std::vector<ConvSpec> v;
+    v.push_back({3, 64});
+    for (int b = 0; b < num_block; ++b)
+        for (int r = 0; r < 3; ++r)
+            for (int k = 1; k <= 5; ++k) v.push_back({64 + (k - 1) * 32, k < 5 ? 32 : 64});
+    v.push_back({64, 64});   // conv_body
+    v.push_back({64, 64});   // conv_up1
+    v.push_back({64, 64});   // conv_up2
+    v.push_back({64, 64});   // conv_hr
+    v.push_back({64, 3});    // conv_last
+    return v;
+}
+
+int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
+    if (h->scratch_bytes[slot] >= bytes) return S2SR_OK;
+    if (h->d_scratch[slot]) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->d_scratch[slot]));
+        h->d_scratch[slot] = nullptr;
+        h->scratch_bytes[slot] = 0;
+    }
+    HIPCHK(h, hipMalloc(&h->d_scratch[slot], bytes));
+    h->scratch_bytes[slot] = bytes;
+    return S2SR_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
+    Workspace& w = h->ws;
+    if (w.base && w.G >= G && w.H == H && w.W == W) return S2SR_OK;
+    if (w.base) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(w.base));
+        w = Workspace();
+    }
+    w.G = G; w.H = H; w.W = W;
+    w.Hp = padded(H); w.Wp = padded(W);
+    w.Hp2 = padded(2 * H); w.Wp2 = padded(2 * W);
+    w.Hp4 = padded(4 * H); w.Wp4 = padded(4 * W);
+    const size_t px1 = (size_t)G * w.Hp * w.Wp, px2 = (size_t)G * w.Hp2 * w.Wp2, px4 = (size_t)G * w.Hp4 * w.Wp4;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
+    const size_t oP0 = take(px1 * 64), oX0 = take(px1 * 128), oX1 = take(px1 * 128), oG = take(px1 * 256),
+                 oU0 = take(px1 * 128), oT = take(px1 * 256), oR = take(px1 * 256), oF = take(px1 * 256),
+                 oU1 = take(px2 * 128), oU2 = take(px4 * 128), oU3 = take(px4 * 128);
+    w.bytes = off;
+    HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
+    HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
+    HIPCHK(h, hipDeviceSynchronize());
+    w.P0 = w.base + oP0; w.X[0] = w.base + oX0; w.X[1] = w.base + oX1; w.Gd = w.base + oG; w.U0 = w.base + oU0;
+    w.T = (float*)(w.base + oT); w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
+    w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
+    return S2SR_OK;
+}
+
+hipEvent_t get_event(s2sr_handle* h) {
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct Scope {   // brackets one launch with events when profiling is on
+    s2sr_handle* h;
+    hipStream_t st;
+    EvRec r;
+    bool on;
+    Scope(s2sr_handle* h_, hipStream_t st_, int fam, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+        if (!on) return;
+        r.fam = fam; r.flops = flops; r.bytes = bytes;
+        r.e0 = get_event(h); r.e1 = get_event(h);
+        hipEventRecord(r.e0, st);
+    }
+    ~Scope() {
+        if (!on) return;
+        hipEventRecord(r.e1, st);
+        h->evs.push_back(r);
+    }
+};
+
+int collect_events(s2sr_handle* h) {
+    if (h->evs.empty()) return S2SR_OK;
+    HIPCHK(h, hipDeviceSynchronize());
+    for (EvRec& r : h->evs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        s2sr_kstat& s = h->stats[r.fam];
+        s.launches += 1; s.total_ms += ms; s.flops += r.flops; s.bytes += r.bytes;
+        h->ev_pool.push_back(r.e0);
+        h->ev_pool.push_back(r.e1);
+    }
+    h->evs.clear();
+    return S2SR_OK;
+}
+
+// one conv launch of the fp16 path
+int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParams p, int epi, bool up) {
+    p.wpack = cw.d_wpack;
+    p.bias = cw.d_bias;
+    p.nchunks = cw.nchunks;
+    if (p.split <= 0 || p.split > p.nchunks) p.split = p.nchunks;
+    if (!p.src1) { p.src1 = p.src0; p.rec1 = p.rec0; }
+    const double px = (double)p.N * p.H * p.W;
+    const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
+    double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
+    if (epi == EPI_LAST) bytes += px * 3.0 * ((p.out_u8 ? 1.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0));
+    else bytes += px * cw.cout * 2.0;
+    if (epi == EPI_RDB5) bytes += px * 64 * 8.0;
+    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * 16.0;
+    if (epi == EPI_FIRST) bytes += px * 64 * 12.0;
+    if (epi == EPI_BODY) bytes += px * 64 * 4.0;
+    Scope sc(h, st, fam, flops, bytes);
+    HIPCHK(h, launch_conv_f16(p, cw.ct, epi, up, st));
+    return S2SR_OK;
+}
+
+// The layer schedule for `n` images already packed into ws.P0.  Exactly the op order of
+// RRDBNet.forward (cnn_super_resolution.py:140-158) with ResidualDenseBlock / RRDB inlined
+// (:85-91, :103-107); the torch.cat of the dense block is the channel layout
+// [X(64) | Gd(128)] read by the loader, never a copy.
+int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f32, uint8_t* d_out_u8) {
+    Workspace& w = h->ws;
+    const int nb = h->cfg.num_block;
+    ConvParams b{};
+    b.N = n; b.H = H; b.W = W; b.Hp = w.Hp; b.Wp = w.Wp; b.sHp = w.Hp; b.sWp = w.Wp;
+    b.T = w.T; b.R = w.R; b.F = w.F;
+    int ci = 0;
+    {   // conv_first: 3 -> 64 (input padded to one 32-channel chunk)
+        ConvParams p = b;
+        p.src0 = w.P0; p.rec0 = 64; p.dst = w.X[0]; p.dst_rec = 128; p.dst_coff = 0; p.in_scale = 1.0f / 255.0f;
+        int rc = run_conv(h, st, F_FIRST, h->convs[ci++], p, EPI_FIRST, false);
+        if (rc) return rc;
+    }
+    int cur = 0;
+    for (int blk = 0; blk < nb; ++blk)
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 1; k <= 4; ++k) {
+                ConvParams p = b;
+                p.src0 = w.X[cur]; p.rec0 = 128; p.src1 = w.Gd; p.rec1 = 256; p.split = 2;
+                p.dst = w.Gd; p.dst_rec = 256; p.dst_coff = (uint32_t)(k - 1) * 64;
+                int rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false);
+                if (rc) return rc;
+            }
+            ConvParams p = b;
+            p.src0 = w.X[cur]; p.rec0 = 128; p.src1 = w.Gd; p.rec1 = 256; p.split = 2;
+            p.dst = w.X[cur ^ 1]; p.dst_rec = 128; p.dst_coff = 0;
+            int rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    {   // conv_body + global skip
+        ConvParams p = b;
+        p.src0 = w.X[cur]; p.rec0 = 128; p.dst = w.U0; p.dst_rec = 128;
+        int rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false);
+        if (rc) return rc;
+    }
+    {   // conv_up1 on nearest-2x
+        ConvParams p{};
+        p.N = n; p.H = 2 * H; p.W = 2 * W; p.Hp = w.Hp2; p.Wp = w.Wp2; p.sHp = w.Hp; p.sWp = w.Wp;
+        p.src0 = w.U0; p.rec0 = 128; p.dst = w.U1; p.dst_rec = 128;
+        int rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true);
+        if (rc) return rc;
+    }
+    {   // conv_up2 on nearest-2x
+        ConvParams p{};
+        p.N = n; p.H = 4 * H; p.W = 4 * W; p.Hp = w.Hp4; p.Wp = w.Wp4; p.sHp = w.Hp2; p.sWp = w.Wp2;
+        p.src0 = w.U1; p.rec0 = 128; p.dst = w.U2; p.dst_rec = 128;
+        int rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true);
+        if (rc) return rc;
+    }
+    ConvParams hr{};
+    hr.N = n; hr.H = 4 * H; hr.W = 4 * W; hr.Hp = w.Hp4; hr.Wp = w.Wp4; hr.sHp = w.Hp4; hr.sWp = w.Wp4;
+    {
+        ConvParams p = hr;
+        p.src0 = w.U2; p.rec0 = 128; p.dst = w.U3; p.dst_rec = 128;
+        int rc = run_conv(h, st, F_HR, h->convs[ci++], p, EPI_LRELU, false);
+        if (rc) return rc;
+    }
+    {
+        ConvParams p = hr;
+        p.src0 = w.U3; p.rec0 = 128; p.out_f32 = d_out_f32; p.out_u8 = d_out_u8; p.cout = 3;
+        int rc = run_conv(h, st, F_LAST, h->convs[ci++], p, EPI_LAST, false);
+        if (rc) return rc;
+    }
+    return S2SR_OK;
+}
+
+int group_size(const s2sr_handle* h, int B, int H, int W) {
+    int g = h->cfg.group > 0 ? h->cfg.group : 8;
+    // keep one plane of one group addressable and the workspace modest (<= ~24 GiB)
+    const double per_img = (double)padded(H) * padded(W) * 1472.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
+                           (double)padded(4 * H) * padded(4 * W) * 256.0;
+    while (g > 1 && per_img * g > 24.0 * 1024 * 1024 * 1024) --g;
+    if (g > B) g = B;
+    return g < 1 ? 1 : g;
+}
+
+// [B,th,tw,3] u8 (device) -> u8 [B,4th,4tw,3] and/or f32 [B,3,4th,4tw] (device)
+int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const float* d_x_f32, int B, int th, int tw,
+                uint8_t* d_out_u8, float* d_out_f32) {
+    if (!h->has_weights) return fail(h, S2SR_E_NOWEIGHTS, "s2sr_load_weights has not been called");
+    if (B <= 0 || th <= 0 || tw <= 0) return fail(h, S2SR_E_INVALID, "bad batch/tile dims");
+    if (h->cfg.precision != S2SR_PREC_F16) return fail(h, S2SR_E_INVALID, "precision mode not built");
+    const int G = group_size(h, B, th, tw);
+    int rc = ensure_workspace(h, G, th, tw);
+    if (rc) return rc;
+    Workspace& w = h->ws;
+    const size_t opx = (size_t)16 * th * tw;
+    for (int g0 = 0; g0 < B; g0 += G) {
+        const int n = (B - g0 < G) ? (B - g0) : G;
+        {
+            Scope sc(h, st, F_PACK, 0.0, (double)n * th * tw * (3.0 + 8.0));
+            if (d_tiles) HIPCHK(h, launch_pack_u8(d_tiles + (size_t)g0 * th * tw * 3, n, th, tw, w.P0, w.Hp, w.Wp, st));
+            else HIPCHK(h, launch_pack_f32_nchw(d_x_f32 + (size_t)g0 * 3 * th * tw, n, 3, th, tw, 255.0f, w.P0, 32, w.Hp, w.Wp, st));
+        }
+        rc = run_net(h, st, n, th, tw, d_out_f32 ? d_out_f32 + (size_t)g0 * 3 * opx : nullptr,
+                     d_out_u8 ? d_out_u8 + (size_t)g0 * 3 * opx : nullptr);
+        if (rc) return rc;
+    }
+    return S2SR_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char* s2sr_version(void) { return "s2sr 0.1 (gfx950, fp16-MFMA implicit-GEMM conv)"; }
+
+int s2sr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t s2sr_expected_blob_floats(int32_t num_block) {
+    size_t n = 0;
+    for (const ConvSpec& s : conv_specs(num_block)) n += (size_t)s.cin * s.cout * 9 + s.cout;
+    return n;
+}
+
+const char* s2sr_last_error(const s2sr_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
+    if (!cfg || !out) return fail(nullptr, S2SR_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->num_block <= 0 || cfg->num_feat != 64 || cfg->num_grow != 32 || cfg->scale != 4)
+        return fail(nullptr, S2SR_E_INVALID, "unsupported net shape (need num_feat=64, num_grow=32, scale=4)");
+    if (cfg->precision != S2SR_PREC_F16 && cfg->precision != S2SR_PREC_F32)
+        return fail(nullptr, S2SR_E_INVALID, "unknown precision");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, S2SR_E_NODEVICE, "no HIP device visible; libs2sr has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, S2SR_E_INVALID, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, S2SR_E_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, S2SR_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950-only");
+    s2sr_handle* h = new s2sr_handle();
+    h->cfg = *cfg;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
+    }
+    for (int i = 0; i < F_COUNT; ++i) {
+        memset(&h->stats[i], 0, sizeof(s2sr_kstat));
+        snprintf(h->stats[i].name, sizeof h->stats[i].name, "%s", kFamName[i]);
+    }
+    *out = h;
+    return S2SR_OK;
+}
+
+void s2sr_destroy(s2sr_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (ConvW& c : h->convs) {
+        if (c.d_wpack) hipFree(c.d_wpack);
+        if (c.d_bias) hipFree(c.d_bias);
+    }
+    if (h->ws.base) hipFree(h->ws.base);
+    for (int i = 0; i < 6; ++i)
+        if (h->d_scratch[i]) hipFree(h->d_scratch[i]);
+    for (EvRec& r : h->evs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
+    if (!h || !blob) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const std::vector<ConvSpec> specs = conv_specs(h->cfg.num_block);
+    const size_t want = s2sr_expected_blob_floats(h->cfg.num_block);
+    if (n_floats != want) {
+        char b[160];
+        snprintf(b, sizeof b, "weight blob has %zu floats, a %d-block net needs %zu", n_floats, h->cfg.num_block, want);
+        return fail(h, S2SR_E_BADBLOB, b);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (ConvW& c : h->convs) {
+        if (c.d_wpack) hipFree(c.d_wpack);
+        if (c.d_bias) hipFree(c.d_bias);
+    }
+    h->convs.clear();
+    h->has_weights = false;
+    const float* pw = blob;
+    std::vector<char> tmp;
+    for (const ConvSpec& s : specs) {
+        ConvW cw;
+        cw.cin = s.cin; cw.cout = s.cout; cw.nchunks = (s.cin + 31) / 32; cw.ct = (s.cout + 31) / 32;
+        const size_t wb = conv_wpack_bytes(s.cin, s.cout);
+        tmp.resize(wb);
+        pack_conv_weights(pw, s.cin, s.cout, 1.0f, tmp.data());
+        pw += (size_t)s.cin * s.cout * 9;
+        HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
+        HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
+        float bias[64] = {0};
+        memcpy(bias, pw, sizeof(float) * s.cout);
+        pw += s.cout;
+        HIPCHK(h, hipMalloc((void**)&cw.d_bias, sizeof bias));
+        HIPCHK(h, hipMemcpy(cw.d_bias, bias, sizeof bias, hipMemcpyHostToDevice));
+        h->convs.push_back(cw);
+    }
+    h->has_weights = true;
+    return S2SR_OK;
+}
+
+int s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t scale, s2sr_window* out, int32_t cap,
+                    int32_t* n) {
+    if (H <= 0 || W <= 0 || tile <= 0 || pad < 0 || scale <= 0 || !n) return S2SR_E_INVALID;
+    const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
+    *n = nx * ny;
+    if (!out) return S2SR_OK;
+    if (cap < nx * ny) return S2SR_E_CAPACITY;
+    const int win = tile + 2 * pad, op = pad * scale;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            s2sr_window& w = out[y * nx + x];
+            // far edge first, then pull the near edge in so the window keeps its full extent
+            w.x2 = (x * tile + win < W) ? x * tile + win : W;
+            w.y2 = (y * tile + win < H) ? y * tile + win : H;
+            w.x1 = (w.x2 - win > 0) ? w.x2 - win : 0;
+            w.y1 = (w.y2 - win > 0) ? w.y2 - win : 0;
+            // the halo is dropped on every side that has a neighbouring tile INDEX
+            w.crop_left = x > 0 ? op : 0;
+            w.crop_top = y > 0 ? op : 0;
+            w.crop_right = x < nx - 1 ? op : 0;
+            w.crop_bottom = y < ny - 1 ? op : 0;
+            w.ox1 = w.x1 * scale + w.crop_left;
+            w.oy1 = w.y1 * scale + w.crop_top;
+            w.ox2 = w.x2 * scale - w.crop_right;
+            w.oy2 = w.y2 * scale - w.crop_bottom;
+        }
+    return S2SR_OK;
+}
+
+int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, int32_t th, int32_t tw, void* d_out,
+                              void* stream) {
+    if (!h || !d_tiles || !d_out) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return forward_dev(h, st, (const uint8_t*)d_tiles, nullptr, B, th, tw, (uint8_t*)d_out, nullptr);
+}
+
+int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, uint8_t* out) {
+    if (!h || !tiles || !out) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t ib = (size_t)B * th * tw * 3, ob = ib * 16;
+    int rc = ensure_scratch(h, 0, ib);
+    if (rc) return rc;
+    rc = ensure_scratch(h, 1, ob);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
+    rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0], nullptr, B, th, tw, (uint8_t*)h->d_scratch[1], nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return S2SR_OK;
+}
+
+int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32_t W, float* y) {
+    if (!h || !x || !y) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t ib = (size_t)N * 3 * H * W * 4, ob = ib * 16;
+    int rc = ensure_scratch(h, 0, ib);
+    if (rc) return rc;
+    rc = ensure_scratch(h, 1, ob);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], x, ib, hipMemcpyHostToDevice, h->stream));
+    rc = forward_dev(h, h->stream, nullptr, (const float*)h->d_scratch[0], N, H, W, nullptr, (float*)h->d_scratch[1]);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(y, h->d_scratch[1], ob, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return S2SR_OK;
+}
+
+// RealESRGAN.enhance (cnn_super_resolution.py:217-234) incl. _tile_process (:236-280)
+static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int tile, int pad, uint8_t* out_u8,
+                        float* out_f32) {
+    if (!h || !img || (!out_u8 && !out_f32) || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const int scale = 4, OH = H * scale, OW = W * scale;
+    const size_t ib = (size_t)H * W * 3, opx = (size_t)OH * OW * 3;
+    int rc;
+    if ((rc = ensure_scratch(h, 0, ib))) return rc;
+    if ((rc = ensure_scratch(h, 1, opx * (out_f32 ? 4 : 1)))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], img, ib, hipMemcpyHostToDevice, st));
+    const bool tiled = (long long)H * W > (long long)tile * tile * 4;   // strict '>' (:226)
+    if (!tiled) {
+        if (out_f32) {
+            // net output is NCHW; enhance() returns HWC -> stitch with an identity map
+            if ((rc = ensure_scratch(h, 2, opx * 4))) return rc;
+            rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[0], nullptr, 1, H, W, nullptr, (float*)h->d_scratch[2]);
+            if (rc) return rc;
+            std::vector<int32_t> rm(2 * OH), cm(2 * OW);
+            for (int i = 0; i < OH; ++i) { rm[2 * i] = 0; rm[2 * i + 1] = i; }
+            for (int i = 0; i < OW; ++i) { cm[2 * i] = 0; cm[2 * i + 1] = i; }
+            if ((rc = ensure_scratch(h, 3, (rm.size() + cm.size()) * 4))) return rc;
+            int32_t* d_rm = (int32_t*)h->d_scratch[3];
+            int32_t* d_cm = d_rm + rm.size();
+            HIPCHK(h, hipMemcpyAsync(d_rm, rm.data(), rm.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipStreamSynchronize(st));   // rm/cm are stack-owned host buffers
+            HIPCHK(h, launch_stitch_f32((const float*)h->d_scratch[2], 1, OH, OW, d_rm, d_cm, OH, OW, (float*)h->d_scratch[1], st));
+        } else {
+            rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[0], nullptr, 1, H, W, (uint8_t*)h->d_scratch[1], nullptr);
+            if (rc) return rc;
+        }
+    } else {
+        int T = 0;
+        s2sr_plan_tiles(H, W, tile, pad, scale, nullptr, 0, &T);
+        std::vector<s2sr_window> wins(T);
+        s2sr_plan_tiles(H, W, tile, pad, scale, wins.data(), T, &T);
+        const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
+        const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;   // all windows share one shape
+        std::vector<int32_t> rects(4 * T), rm(2 * OH, -1), cm(2 * OW, -1);
+        for (int t = 0; t < T; ++t) {
+            rects[4 * t] = wins[t].y1; rects[4 * t + 1] = wins[t].y2; rects[4 * t + 2] = wins[t].x1; rects[4 * t + 3] = wins[t].x2;
+        }
+        // last window in loop order wins (:278): ascending index, later entries overwrite the map
+        for (int y = 0; y < ny; ++y) {
+            const s2sr_window& w = wins[y * nx];
+            for (int oy = w.oy1; oy < w.oy2; ++oy) { rm[2 * oy] = y; rm[2 * oy + 1] = oy - w.oy1 + w.crop_top; }
+        }
+        for (int x = 0; x < nx; ++x) {
+            const s2sr_window& w = wins[x];
+            for (int ox = w.ox1; ox < w.ox2; ++ox) { cm[2 * ox] = x; cm[2 * ox + 1] = ox - w.ox1 + w.crop_left; }
+        }
+        const size_t tin = (size_t)T * wh * ww * 3, tout = tin * 16;
+        if ((rc = ensure_scratch(h, 2, tin))) return rc;
+        if ((rc = ensure_scratch(h, 4, tout * (out_f32 ? 4 : 1)))) return rc;
+        if ((rc = ensure_scratch(h, 3, (rects.size() + rm.size() + cm.size()) * 4))) return rc;
+        int32_t* d_rects = (int32_t*)h->d_scratch[3];
+        int32_t* d_rm = d_rects + rects.size();
+        int32_t* d_cm = d_rm + rm.size();
+        HIPCHK(h, hipMemcpyAsync(d_rects, rects.data(), rects.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(d_rm, rm.data(), rm.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, launch_gather_windows((const uint8_t*)h->d_scratch[0], H, W, d_rects, T, wh, ww, (uint8_t*)h->d_scratch[2], st));
+        rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[2], nullptr, T, wh, ww, out_f32 ? nullptr : (uint8_t*)h->d_scratch[4],
+                         out_f32 ? (float*)h->d_scratch[4] : nullptr);
+        if (rc) return rc;
+        if (out_f32) HIPCHK(h, launch_stitch_f32((const float*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (float*)h->d_scratch[1], st));
+        else HIPCHK(h, launch_stitch_u8((const uint8_t*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (uint8_t*)h->d_scratch[1], st));
+    }
+    if (out_f32) HIPCHK(h, hipMemcpyAsync(out_f32, h->d_scratch[1], opx * 4, hipMemcpyDeviceToHost, st));
+    else HIPCHK(h, hipMemcpyAsync(out_u8, h->d_scratch[1], opx, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return S2SR_OK;
+}
+
+int s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, uint8_t* out) {
+    return enhance_impl(h, img, H, W, tile, pad, out, nullptr);
+}
+
+int s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
+    return enhance_impl(h, img, H, W, tile, pad, nullptr, out);
+}
+
+int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
+                                  const s2sr_pp_params* prm, void* d_out, void* stream) {
+    if (!h || !d_rgb || !d_out || !prm || B <= 0 || H <= 0 || W <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const size_t wb = postprocess_work_bytes(B, H, W, *prm);
+    int rc = ensure_scratch(h, 5, wb);
+    if (rc) return rc;
+    Scope sc(h, st, F_POST, 0.0, (double)B * H * W * 9.0);
+    HIPCHK(h, launch_postprocess((const uint8_t*)d_rgb, B, H, W, *prm, (uint8_t*)d_out, h->d_scratch[5], wb, st));
+    return S2SR_OK;
+}
+
+int s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, const s2sr_pp_params* prm, uint8_t* out) {
+    if (!h || !rgb || !out || !prm || H <= 0 || W <= 0) return S2SR_E_INVALID;
+    const size_t nb = (size_t)H * W * 3;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        int rc = ensure_scratch(h, 0, nb);
+        if (rc) return rc;
+        if ((rc = ensure_scratch(h, 1, nb))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgb, nb, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = s2sr_postprocess_batch_u8_dev(h, h->d_scratch[0], 1, H, W, prm, h->d_scratch[1], nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], nb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return S2SR_OK;
+}
+
+int s2sr_set_profiling(s2sr_handle* h, int32_t on) {
+    if (!h) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->prof = on != 0;
+    return S2SR_OK;
+}
+
+int s2sr_reset_kernel_stats(s2sr_handle* h) {
+    if (!h) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = collect_events(h);
+    for (int i = 0; i < F_COUNT; ++i) { h->stats[i].launches = 0; h->stats[i].total_ms = 0; h->stats[i].flops = 0; h->stats[i].bytes = 0; }
+    return rc;
+}
+
+int s2sr_get_kernel_stats(s2sr_handle* h, s2sr_kstat* out, int32_t cap, int32_t* n) {
+    if (!h || !n) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = collect_events(h);
+    if (rc) return rc;
+    *n = F_COUNT;
+    if (!out) return S2SR_OK;
+    if (cap < F_COUNT) return S2SR_E_CAPACITY;
+    for (int i = 0; i < F_COUNT; ++i) out[i] = h->stats[i];
+    return S2SR_OK;
+}
+
+int s2sr_synchronize(s2sr_handle* h) {
+    if (!h) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipDeviceSynchronize());
+    return S2SR_OK;
+}
+
+int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W, const float* weight,
+                    const float* bias, int32_t Cout, int32_t upsample, int32_t act, float* y) {
+    if (!h || !x || !weight || !bias || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 64 || H <= 0 || W <= 0)
+        return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const int Cp = roundup32(Cin);
+    const int OHh = upsample ? 2 * H : H, OWw = upsample ? 2 * W : W;
+    const int sHp = padded(H), sWp = padded(W), Hp = padded(OHh), Wp = padded(OWw);
+    const size_t plane_b = (size_t)N * sHp * sWp * Cp * 2, xb = (size_t)N * Cin * H * W * 4,
+                 yb = (size_t)N * Cout * OHh * OWw * 4, wb = conv_wpack_bytes(Cin, Cout);
+    char *d_plane = nullptr, *d_w = nullptr;
+    float *d_x = nullptr, *d_y = nullptr, *d_b = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_plane, plane_b));
+    HIPCHK(h, hipMalloc((void**)&d_x, xb));
+    HIPCHK(h, hipMalloc((void**)&d_y, yb));
+    HIPCHK(h, hipMalloc((void**)&d_w, wb));
+    HIPCHK(h, hipMalloc((void**)&d_b, 64 * 4));
+    std::vector<char> wp(wb);
+    pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
+    float bb[64] = {0};
+    memcpy(bb, bias, Cout * sizeof(float));
+    HIPCHK(h, hipMemsetAsync(d_plane, 0, plane_b, st));
+    HIPCHK(h, hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_w, wp.data(), wb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_b, bb, sizeof bb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, launch_pack_f32_nchw(d_x, N, Cin, H, W, 1.0f, d_plane, Cp, sHp, sWp, st));
+    ConvParams p{};
+    p.src0 = d_plane; p.src1 = d_plane; p.rec0 = p.rec1 = (uint32_t)Cp * 2; p.nchunks = Cp / 32; p.split = p.nchunks;
+    p.wpack = d_w; p.bias = d_b; p.N = N; p.H = OHh; p.W = OWw; p.Hp = Hp; p.Wp = Wp; p.sHp = sHp; p.sWp = sWp;
+    p.out_f32 = d_y; p.cout = Cout; p.act = act;
+    HIPCHK(h, launch_conv_f16(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
+    HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
+    return S2SR_OK;
+}
+
+}  // extern "C"

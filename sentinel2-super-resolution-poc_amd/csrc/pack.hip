@@ -1,0 +1,144 @@
+// Data-movement kernels around the conv stack: HBM-bound byte work, one element per thread,
+// coalesced on the side that moves the most bytes.
+//   pack_u8            : [N,H,W,3] u8 -> fp16 NHWC(32) plane with zero halo; replaces
+//                        `img.astype(float32)/255` + permute (cnn_super_resolution.py:220-222);
+//                        values stay the exact integers 0..255, the 1/255 lives in conv_first.
+//   gather_windows     : cut the _tile_process windows (cnn_super_resolution.py:249-256)
+//   stitch_*           : crop + paste with the reference's overwrite order (:259-278)
+#include "s2sr_internal.h"
+
+namespace s2sr {
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void pack_u8_kernel(const uint8_t* __restrict__ in, int N, int H, int W, char* __restrict__ plane, int Hp,
+                               int Wp) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t r = i / W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        const uint8_t* s = in + i * 3;
+        f16x4 v;
+        v[0] = (f16)(float)s[0];
+        v[1] = (f16)(float)s[1];
+        v[2] = (f16)(float)s[2];
+        v[3] = (f16)0.f;
+        *(f16x4*)(plane + (((size_t)n * Hp + y + 1) * Wp + x + 1) * 64) = v;
+    }
+}
+
+hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* plane, int Hp, int Wp, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_u8_kernel, dim3(grid), dim3(256), 0, st, d_tiles, N, H, W, plane, Hp, Wp);
+    return hipGetLastError();
+}
+
+__global__ void pack_f32_nchw_kernel(const float* __restrict__ x, int N, int C, int H, int W, float scale,
+                                     char* __restrict__ plane, int Cp, int Hp, int Wp) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        size_t r = i / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        f16* d = (f16*)plane + (((size_t)n * Hp + y + 1) * Wp + xx + 1) * Cp + c;
+        *d = (f16)(x[i] * scale);
+    }
+}
+
+hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* plane, int Cp, int Hp,
+                                int Wp, hipStream_t st) {
+    const size_t total = (size_t)N * C * H * W;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_f32_nchw_kernel, dim3(grid), dim3(256), 0, st, d_x, N, C, H, W, scale, plane, Cp, Hp, Wp);
+    return hipGetLastError();
+}
+
+__global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
+                                      int T, int wh, int ww, uint8_t* __restrict__ tiles) {
+    const size_t total = (size_t)T * wh * ww * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        size_t r = i / 3;
+        const int x = (int)(r % ww);
+        r /= ww;
+        const int y = (int)(r % wh);
+        const int t = (int)(r / wh);
+        const int y1 = rects[t * 4 + 0], x1 = rects[t * 4 + 2];
+        tiles[i] = img[((size_t)(y1 + y) * W + (x1 + x)) * 3 + c];
+    }
+}
+
+hipError_t launch_gather_windows(const uint8_t* d_img, int H, int W, const int32_t* d_rects, int T, int wh, int ww,
+                                 uint8_t* d_tiles, hipStream_t st) {
+    const size_t total = (size_t)T * wh * ww * 3;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_windows_kernel, dim3(grid), dim3(256), 0, st, d_img, H, W, d_rects, T, wh, ww, d_tiles);
+    return hipGetLastError();
+}
+
+// rowmap[2*oy] = window-row index ty (or -1: not covered), rowmap[2*oy+1] = row inside that
+// window's output; colmap likewise with tx.
+// "Later windows overwrite" (cnn_super_resolution.py:278) == the LAST (ty, tx) in loop order
+// whose paste rectangle contains the pixel; paste rectangles are row-range x column-range
+// products, so that is (last covering ty, last covering tx) -- resolved on the host into
+// these maps, which makes the paste race-free and order-independent.
+__global__ void stitch_u8_kernel(const uint8_t* __restrict__ tiles, int oth, int otw, const int32_t* __restrict__ rowmap,
+                                 const int32_t* __restrict__ colmap, int tilesX, int OH, int OW,
+                                 uint8_t* __restrict__ out) {
+    const size_t total = (size_t)OH * OW * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const size_t r = i / 3;
+        const int ox = (int)(r % OW);
+        const int oy = (int)(r / OW);
+        const int ty = rowmap[2 * oy], sy = rowmap[2 * oy + 1];
+        const int tx = colmap[2 * ox], sx = colmap[2 * ox + 1];
+        uint8_t v = 0;   // reference output starts as zeros (cnn_super_resolution.py:242)
+        if (ty >= 0 && tx >= 0) v = tiles[(((size_t)(ty * tilesX + tx) * oth + sy) * otw + sx) * 3 + c];
+        out[i] = v;
+    }
+}
+
+__global__ void stitch_f32_kernel(const float* __restrict__ tiles, int oth, int otw, const int32_t* __restrict__ rowmap,
+                                  const int32_t* __restrict__ colmap, int tilesX, int OH, int OW,
+                                  float* __restrict__ out) {
+    const size_t total = (size_t)OH * OW * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        const size_t r = i / 3;
+        const int ox = (int)(r % OW);
+        const int oy = (int)(r / OW);
+        const int ty = rowmap[2 * oy], sy = rowmap[2 * oy + 1];
+        const int tx = colmap[2 * ox], sx = colmap[2 * ox + 1];
+        float v = 0.f;
+        if (ty >= 0 && tx >= 0) v = tiles[(((size_t)(ty * tilesX + tx) * 3 + c) * oth + sy) * otw + sx];
+        out[i] = v;
+    }
+}
+
+hipError_t launch_stitch_u8(const uint8_t* d_tiles, int tilesX, int oth, int otw, const int32_t* d_rowmap,
+                            const int32_t* d_colmap, int OH, int OW, uint8_t* d_out, hipStream_t st) {
+    const size_t total = (size_t)OH * OW * 3;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(stitch_u8_kernel, dim3(grid), dim3(256), 0, st, d_tiles, oth, otw, d_rowmap, d_colmap, tilesX, OH, OW,
+                       d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_stitch_f32(const float* d_tiles, int tilesX, int oth, int otw, const int32_t* d_rowmap,
+                             const int32_t* d_colmap, int OH, int OW, float* d_out, hipStream_t st) {
+    const size_t total = (size_t)OH * OW * 3;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(stitch_f32_kernel, dim3(grid), dim3(256), 0, st, d_tiles, oth, otw, d_rowmap, d_colmap, tilesX, OH,
+                       OW, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace s2sr

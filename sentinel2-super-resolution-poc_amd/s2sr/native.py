@@ -1,0 +1,246 @@
+"""ctypes binding of libs2sr.so (include/s2sr.h).
+
+This is the only place Python touches the native library.  There is NO fallback: if the
+shared object is missing or no gfx950 device is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("S2SR_LIB", _HERE.parent / "csrc" / "libs2sr.so"))
+
+PREC_F16, PREC_F32 = 0, 1
+_ERR = {-1: "invalid argument", -2: "HIP error", -3: "weights not loaded", -4: "bad weight blob",
+        -5: "no gfx950 device (no CPU fallback exists)", -6: "buffer too small"}
+
+
+class S2srError(RuntimeError):
+    pass
+
+
+class _Config(C.Structure):
+    _fields_ = [("num_block", C.c_int32), ("num_feat", C.c_int32), ("num_grow", C.c_int32), ("scale", C.c_int32),
+                ("precision", C.c_int32), ("device", C.c_int32), ("group", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Window(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("y1", "y2", "x1", "x2", "crop_top", "crop_bottom", "crop_left",
+                                         "crop_right", "oy1", "oy2", "ox1", "ox2")]
+
+
+class PPParams(C.Structure):
+    _fields_ = [("clahe_clip", C.c_float), ("clahe_grid", C.c_int32), ("blur_sigma", C.c_float),
+                ("w_img", C.c_float), ("w_blur", C.c_float), ("hue_lo", C.c_int32), ("hue_hi", C.c_int32),
+                ("sat_gain", C.c_float), ("stages", C.c_int32)]
+
+
+class KStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# constants of the two post-process variants (reference wow_sr.py:191-205, farm_sr.py:100,170-178)
+def pp_wow() -> PPParams:
+    return PPParams(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.2, 7)
+
+
+def pp_farm() -> PPParams:
+    return PPParams(2.5, 8, 1.5, 2.2, -1.2, 35, 85, 1.3, 7)
+
+
+_lib = None
+
+_PROTOS = {
+    "s2sr_version": (C.c_char_p, []),
+    "s2sr_device_count": (C.c_int, []),
+    "s2sr_create": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_void_p)]),
+    "s2sr_destroy": (None, [C.c_void_p]),
+    "s2sr_last_error": (C.c_char_p, [C.c_void_p]),
+    "s2sr_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "s2sr_expected_blob_floats": (C.c_size_t, [C.c_int32]),
+    "s2sr_plan_tiles": (C.c_int, [C.c_int32] * 5 + [C.POINTER(Window), C.c_int32, C.POINTER(C.c_int32)]),
+    "s2sr_forward_batch_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_forward_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p]),
+    "s2sr_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_enhance_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_postprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
+    "s2sr_postprocess_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                C.POINTER(PPParams), C.c_void_p, C.c_void_p]),
+    "s2sr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "s2sr_get_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KStat), C.c_int32, C.POINTER(C.c_int32)]),
+    "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
+    "s2sr_synchronize": (C.c_int, [C.c_void_p]),
+    "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
+                        [C.c_int32] * 3 + [C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def load_library():
+    """dlopen libs2sr.so and attach prototypes.  Raises if it is not built: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise S2srError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"or `make -C {LIB_PATH.parent}`.  There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError here == ABI drift, let it surface
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def plan_tiles(H: int, W: int, tile: int = 256, pad: int = 10, scale: int = 4) -> List[Window]:
+    """Pure host call (works without a GPU): window plan of `_tile_process`."""
+    lib = load_library()
+    n = C.c_int32(0)
+    rc = lib.s2sr_plan_tiles(H, W, tile, pad, scale, None, 0, C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_plan_tiles: {_ERR.get(rc, rc)}")
+    arr = (Window * n.value)()
+    rc = lib.s2sr_plan_tiles(H, W, tile, pad, scale, arr, n.value, C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_plan_tiles: {_ERR.get(rc, rc)}")
+    return list(arr)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One native handle == one GPU.  Thread-safe (the library serialises calls per handle)."""
+
+    def __init__(self, num_block: int = 23, precision: int = PREC_F16, device: int = 0, group: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.num_block = num_block
+        cfg = _Config(num_block, 64, 32, 4, precision, device, group, 0)
+        rc = self._lib.s2sr_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            msg = self._lib.s2sr_last_error(None)
+            raise S2srError(f"s2sr_create failed ({_ERR.get(rc, rc)}): {msg.decode() if msg else ''}")
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc:
+            msg = self._lib.s2sr_last_error(self._h)
+            raise S2srError(f"{what} failed ({_ERR.get(rc, rc)}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.s2sr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ----------------------------------------------------------------------------
+    def load_blob(self, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(self._lib.s2sr_load_weights(self._h, _ptr(blob), blob.size), "s2sr_load_weights")
+
+    def load_state_dict(self, sd):
+        from .weights import flatten_state_dict
+        self.load_blob(flatten_state_dict(sd, self.num_block))
+
+    # -- forward ----------------------------------------------------------------------------
+    def forward_batch_u8(self, tiles: np.ndarray) -> np.ndarray:
+        tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
+        B, h, w, c = tiles.shape
+        assert c == 3
+        out = np.empty((B, 4 * h, 4 * w, 3), dtype=np.uint8)
+        self._check(self._lib.s2sr_forward_batch_u8(self._h, _ptr(tiles), B, h, w, _ptr(out)), "s2sr_forward_batch_u8")
+        return out
+
+    def forward_batch_u8_dev(self, d_in: int, B: int, h: int, w: int, d_out: int, stream: int = 0):
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
+        self._check(self._lib.s2sr_forward_batch_u8_dev(self._h, d_in, B, h, w, d_out, stream or None),
+                    "s2sr_forward_batch_u8_dev")
+
+    def forward_f32(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        N, c, H, W = x.shape
+        assert c == 3
+        y = np.empty((N, 3, 4 * H, 4 * W), dtype=np.float32)
+        self._check(self._lib.s2sr_forward_f32(self._h, _ptr(x), N, H, W, _ptr(y)), "s2sr_forward_f32")
+        return y
+
+    def enhance_u8(self, img: np.ndarray, tile: int = 256, pad: int = 10) -> np.ndarray:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W, c = img.shape
+        assert c == 3
+        out = np.empty((4 * H, 4 * W, 3), dtype=np.uint8)
+        self._check(self._lib.s2sr_enhance_u8(self._h, _ptr(img), H, W, tile, pad, _ptr(out)), "s2sr_enhance_u8")
+        return out
+
+    def enhance_f32(self, img: np.ndarray, tile: int = 256, pad: int = 10) -> np.ndarray:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W, c = img.shape
+        out = np.empty((4 * H, 4 * W, 3), dtype=np.float32)
+        self._check(self._lib.s2sr_enhance_f32(self._h, _ptr(img), H, W, tile, pad, _ptr(out)), "s2sr_enhance_f32")
+        return out
+
+    # -- post-process -----------------------------------------------------------------------
+    def postprocess_u8(self, rgb: np.ndarray, prm: PPParams) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        H, W, c = rgb.shape
+        assert c == 3
+        out = np.empty_like(rgb)
+        self._check(self._lib.s2sr_postprocess_u8(self._h, _ptr(rgb), H, W, C.byref(prm), _ptr(out)),
+                    "s2sr_postprocess_u8")
+        return out
+
+    def postprocess_batch_u8_dev(self, d_in: int, B: int, H: int, W: int, prm: PPParams, d_out: int, stream: int = 0):
+        self._check(self._lib.s2sr_postprocess_batch_u8_dev(self._h, d_in, B, H, W, C.byref(prm), d_out,
+                                                            stream or None), "s2sr_postprocess_batch_u8_dev")
+
+    # -- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._check(self._lib.s2sr_set_profiling(self._h, int(on)), "s2sr_set_profiling")
+
+    def reset_kernel_stats(self):
+        self._check(self._lib.s2sr_reset_kernel_stats(self._h), "s2sr_reset_kernel_stats")
+
+    def kernel_stats(self) -> dict:
+        n = C.c_int32(0)
+        self._check(self._lib.s2sr_get_kernel_stats(self._h, None, 0, C.byref(n)), "s2sr_get_kernel_stats")
+        arr = (KStat * n.value)()
+        self._check(self._lib.s2sr_get_kernel_stats(self._h, arr, n.value, C.byref(n)), "s2sr_get_kernel_stats")
+        return {s.name.decode(): {"launches": s.launches, "total_ms": s.total_ms, "flops": s.flops, "bytes": s.bytes}
+                for s in arr}
+
+    def synchronize(self):
+        self._check(self._lib.s2sr_synchronize(self._h), "s2sr_synchronize")
+
+    # -- test hook --------------------------------------------------------------------------
+    def debug_conv(self, x: np.ndarray, weight: np.ndarray, bias: np.ndarray, upsample: bool = False,
+                   act: bool = False) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        weight = np.ascontiguousarray(weight, dtype=np.float32)
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+        N, cin, H, W = x.shape
+        cout = weight.shape[0]
+        assert weight.shape == (cout, cin, 3, 3) and bias.shape == (cout,)
+        s = 2 if upsample else 1
+        y = np.empty((N, cout, s * H, s * W), dtype=np.float32)
+        self._check(self._lib.s2sr_debug_conv(self._h, _ptr(x), N, cin, H, W, _ptr(weight), _ptr(bias), cout,
+                                              int(upsample), int(act), _ptr(y)), "s2sr_debug_conv")
+        return y
+
+
+def device_count() -> int:
+    return int(load_library().s2sr_device_count())
