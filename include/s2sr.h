@@ -118,6 +118,11 @@ int  s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
 int  s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
                       int32_t tile, int32_t pad, float* out);
 
+/* RealESRGAN._tile_process alone (cnn_super_resolution.py:236-280): always the window plan,
+ * whatever the image size; HWC fp32 out (unquantised). */
+int  s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
+                           int32_t tile, int32_t pad, float* out);
+
 /* replaces _enhance_for_crops (wow_sr.py:187-209) and enhance_local_contrast /
  * apply_unsharp_mask / enhance_vegetation (farm_sr.py:61-108): HxWx3 u8 RGB -> same. */
 int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W,

@@ -1,0 +1,229 @@
+"""Drop-in for the reference module `app.cnn_super_resolution`
+(reference server/app/cnn_super_resolution.py): same public names, constructor arguments,
+attributes and error behaviour, but every pixel is computed by libs2sr.so on an MI355X.
+
+    RealESRGAN(scale=4, device=None, tile_size=256, model_name=None).enhance(img) -> img x4
+
+Differences a maintainer should know (all deliberate):
+  * there is no CPU path: `device="cpu"` (or a box without a gfx950 GPU) raises RuntimeError
+    instead of silently running for minutes on the host (reference :174-177);
+  * weights are never fetched from the network unless S2SR_ALLOW_DOWNLOAD=1; they are looked
+    up as `<model dir>/<model_name>.pth` exactly like the reference (:48-70), and
+    `state_dict=` may be passed directly (tests, synthetic benchmarks);
+  * native engines are cached per (weights, device), so the reference's construct-per-job
+    pattern (wow_sr.py:93-97) costs nothing after the first job.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import threading
+import urllib.request
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from s2sr import native
+from s2sr.weights import MODEL_TABLE, conv_specs, flatten_state_dict, select_params
+
+# Model table -- keys and fields as in the reference (:28-45)
+MODELS = {
+    "realesrgan_x4": {
+        "url": "https://github.com/xinntao/Real-ESRGAN/releases/download/v0.1.0/RealESRGAN_x4plus.pth",
+        "description": "General photos (best quality)",
+        **MODEL_TABLE["realesrgan_x4"],
+    },
+    "realesrgan_anime": {
+        "url": "https://github.com/xinntao/Real-ESRGAN/releases/download/v0.2.2.4/RealESRGAN_x4plus_anime_6B.pth",
+        "description": "Sharp edges (best for text/plates)",
+        **MODEL_TABLE["realesrgan_anime"],
+    },
+}
+
+
+def get_model_dir() -> Path:
+    """`server/models` next to the app package, or $S2SR_MODEL_DIR (reference :48-52)."""
+    d = Path(os.environ.get("S2SR_MODEL_DIR", Path(__file__).resolve().parent.parent / "models"))
+    d.mkdir(parents=True, exist_ok=True)
+    return d
+
+
+def download_weights(model_name: str) -> Path:
+    """Path of `<model_name>.pth`; ValueError for unknown names (reference :55-70)."""
+    if model_name not in MODELS:
+        raise ValueError(f"Unknown model: {model_name}")
+    path = get_model_dir() / f"{model_name}.pth"
+    if not path.exists():
+        if os.environ.get("S2SR_ALLOW_DOWNLOAD") == "1":
+            print(f"Downloading {model_name} weights...")
+            urllib.request.urlretrieve(MODELS[model_name]["url"], path)
+        else:
+            raise FileNotFoundError(
+                f"{path} not found and network download is disabled (set S2SR_ALLOW_DOWNLOAD=1 to fetch "
+                f"{MODELS[model_name]['url']}, or place the file there)")
+    return path
+
+
+# ------------------------------------------------------------------------------------------
+# Parameter containers with the reference's state-dict layout.  They hold weights only;
+# the arithmetic of ResidualDenseBlock / RRDB / RRDBNet.forward lives in csrc/.
+# ------------------------------------------------------------------------------------------
+def _attach(root: nn.Module, dotted: str, leaf: nn.Module) -> None:
+    parts = dotted.split(".")
+    node = root
+    for name in parts[:-1]:
+        if not hasattr(node, name):
+            node.add_module(name, nn.Module())
+        node = getattr(node, name)
+    node.add_module(parts[-1], leaf)
+
+
+class RRDBNet(nn.Module):
+    """Shape-compatible with the reference RRDBNet (:110-158): `load_state_dict(strict=True)`
+    accepts RealESRGAN_x4plus / anime_6B checkpoints.  `forward` runs on the GPU engine."""
+
+    def __init__(self, num_in_ch=3, num_out_ch=3, num_feat=64, num_block=23, num_grow_ch=32, scale=4):
+        super().__init__()
+        if (num_in_ch, num_out_ch, num_feat, num_grow_ch, scale) != (3, 3, 64, 32, 4):
+            raise ValueError("the native path is built for num_in_ch=3, num_out_ch=3, num_feat=64, "
+                             "num_grow_ch=32, scale=4 (the only shapes in MODELS)")
+        self.scale = scale
+        self.num_block = num_block
+        for name, cin, cout, _ in conv_specs(num_block):
+            _attach(self, name, nn.Conv2d(cin, cout, 3, 1, 1))
+        self._engine: Optional[native.Engine] = None
+        self._engine_key = None
+
+    # -- engine management ------------------------------------------------------------------
+    def _fingerprint(self) -> str:
+        h = hashlib.sha1()
+        for k, v in self.state_dict().items():
+            h.update(k.encode())
+            t = v.detach().cpu().contiguous()
+            h.update(t.numpy().tobytes()[:4096])
+            h.update(str(float(t.double().sum())).encode())
+        return h.hexdigest()
+
+    def engine(self, device_index: int = 0) -> native.Engine:
+        key = (self._fingerprint(), device_index)
+        if self._engine is None or self._engine_key != key:
+            self._engine = _engine_for(self.state_dict(), self.num_block, device_index, key[0])
+            self._engine_key = key
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """[N,3,H,W] float in [0,1] -> [N,3,4H,4W] float32 (unclamped), computed on the GPU."""
+        dev = x.device
+        idx = dev.index if dev.type == "cuda" and dev.index is not None else 0
+        y = self.engine(idx).forward_f32(x.detach().float().cpu().numpy())
+        return torch.from_numpy(y).to(dev)
+
+
+_ENGINES: Dict[Tuple[str, int], native.Engine] = {}
+_ENGINES_LOCK = threading.Lock()
+
+
+def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str) -> native.Engine:
+    """One native handle per (weights, GPU), shared by every RealESRGAN object of the process."""
+    with _ENGINES_LOCK:
+        key = (fingerprint, device_index)
+        eng = _ENGINES.get(key)
+        if eng is None:
+            eng = native.Engine(num_block=num_block, device=device_index,
+                                group=int(os.environ.get("S2SR_GROUP", "0")))
+            eng.load_blob(flatten_state_dict(state_dict, num_block))
+            _ENGINES[key] = eng
+        return eng
+
+
+def _resolve_device(device) -> torch.device:
+    if device is None:
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"device {device!r}: this build runs the network on an MI355X only; "
+                           "there is no CPU fallback")
+    return dev if dev.index is not None else torch.device("cuda", 0)
+
+
+class RealESRGAN:
+    """Real-ESRGAN inference wrapper with the reference's interface (:161-280)."""
+
+    def __init__(self, scale: int = 4, device: str = None, tile_size: int = 256, model_name: str = None,
+                 state_dict=None):
+        self.tile_size = tile_size
+        self.tile_pad = 10
+        self.device = _resolve_device(device)
+        print(f"   Device: {self.device}")
+
+        if model_name is None:
+            model_name = f"realesrgan_x{scale}"
+        if model_name not in MODELS:
+            raise ValueError(f"Unknown model: {model_name}. Available: {list(MODELS.keys())}")
+        config = MODELS[model_name]
+        self.scale = config["scale"]
+        self.model_name = model_name
+
+        self.model = RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=config["channels"],
+                             num_block=config["blocks"], num_grow_ch=32, scale=self.scale)
+        if state_dict is None:
+            weights_path = download_weights(model_name)
+            state_dict = select_params(torch.load(weights_path, map_location="cpu"))
+        state_dict = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
+        self.model.load_state_dict(state_dict, strict=True)
+        self.model.eval()
+        self._engine = self.model.engine(self.device.index or 0)
+        print(f"   Loaded {model_name} (x{self.scale})")
+
+    def enhance(self, img: np.ndarray) -> np.ndarray:
+        """HxWx3 uint8 (channel order as given) -> 4Hx4Wx3 uint8.
+
+        Whole-image forward when h*w <= tile_size^2*4, otherwise the reference's window plan
+        (tile_size + 2*tile_pad windows, halo crop, later windows overwrite) -- both inside
+        s2sr_enhance_u8; quantisation is the reference's truncation (:232)."""
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError(f"expected HxWx3 image, got shape {img.shape}")
+        if img.dtype != np.uint8:
+            # the reference divides whatever it gets by 255 (:220); only u8 is on the native path
+            raise TypeError(f"expected uint8 image, got {img.dtype}")
+        return self._engine.enhance_u8(img, tile=self.tile_size, pad=self.tile_pad)
+
+    def _tile_process(self, img: torch.Tensor) -> torch.Tensor:
+        """[1,3,H,W] float in [0,1] -> [1,3,4H,4W] float32 through the tiled path (:236-280)."""
+        u8 = (img[0].permute(1, 2, 0).cpu().numpy() * 255.0).round().clip(0, 255).astype(np.uint8)
+        out = self._engine.tile_process_f32(u8, tile=self.tile_size, pad=self.tile_pad)
+        return torch.from_numpy(out).permute(2, 0, 1).unsqueeze(0)
+
+
+def apply_cnn_sr(input_path: Path, output_path: Path, scale: int = 4) -> Tuple[Path, dict]:
+    """File-level glue of the reference (:283-382): read raster -> enhance -> write raster."""
+    from s2sr import rasterio_lite as rio
+
+    print(f"\nCNN Super-Resolution (Real-ESRGAN x{scale})")
+    input_path = Path(input_path)
+    img, georef = rio.read_rgb_u8(input_path, minmax_eps=1e-6)
+    model = RealESRGAN(scale=scale, tile_size=256)
+    out_bgr = model.enhance(np.ascontiguousarray(img[:, :, ::-1]))
+    out_rgb = np.ascontiguousarray(out_bgr[:, :, ::-1])
+    output_path = Path(output_path)
+    output_path.parent.mkdir(parents=True, exist_ok=True)
+    if georef is not None:
+        final_path = output_path.with_suffix(".tif")
+        rio.write_geotiff_rgb(final_path, out_rgb, georef.scaled(scale))
+    else:
+        final_path = output_path.with_suffix(".png")
+        rio.write_png(final_path, out_rgb)
+    metadata = {
+        "model": f"RealESRGAN_x{scale}",
+        "scale": scale,
+        "input_size": [img.shape[1], img.shape[0]],
+        "output_size": [out_rgb.shape[1], out_rgb.shape[0]],
+        "device": str(model.device),
+        "original_resolution_m": 10.0,
+        "effective_resolution_m": 10.0 / scale,
+    }
+    return final_path, metadata

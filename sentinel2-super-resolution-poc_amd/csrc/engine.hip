@@ -502,7 +502,7 @@ int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32
 
 // RealESRGAN.enhance (cnn_super_resolution.py:217-234) incl. _tile_process (:236-280)
 static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int tile, int pad, uint8_t* out_u8,
-                        float* out_f32) {
+                        float* out_f32, bool force_tiled = false) {
     if (!h || !img || (!out_u8 && !out_f32) || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -513,7 +513,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
     if ((rc = ensure_scratch(h, 0, ib))) return rc;
     if ((rc = ensure_scratch(h, 1, opx * (out_f32 ? 4 : 1)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], img, ib, hipMemcpyHostToDevice, st));
-    const bool tiled = (long long)H * W > (long long)tile * tile * 4;   // strict '>' (:226)
+    const bool tiled = force_tiled || (long long)H * W > (long long)tile * tile * 4;   // strict '>' (:226)
     if (!tiled) {
         if (out_f32) {
             // net output is NCHW; enhance() returns HWC -> stitch with an identity map
@@ -584,6 +584,10 @@ int s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, in
 
 int s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
     return enhance_impl(h, img, H, W, tile, pad, nullptr, out);
+}
+
+int s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
+    return enhance_impl(h, img, H, W, tile, pad, nullptr, out, true);
 }
 
 int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,

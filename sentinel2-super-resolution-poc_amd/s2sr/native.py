@@ -71,6 +71,7 @@ _PROTOS = {
     "s2sr_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_enhance_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_tile_process_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_postprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
     "s2sr_postprocess_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(PPParams), C.c_void_p, C.c_void_p]),
@@ -192,6 +193,14 @@ class Engine:
         H, W, c = img.shape
         out = np.empty((4 * H, 4 * W, 3), dtype=np.float32)
         self._check(self._lib.s2sr_enhance_f32(self._h, _ptr(img), H, W, tile, pad, _ptr(out)), "s2sr_enhance_f32")
+        return out
+
+    def tile_process_f32(self, img: np.ndarray, tile: int = 256, pad: int = 10) -> np.ndarray:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W, c = img.shape
+        out = np.empty((4 * H, 4 * W, 3), dtype=np.float32)
+        self._check(self._lib.s2sr_tile_process_f32(self._h, _ptr(img), H, W, tile, pad, _ptr(out)),
+                    "s2sr_tile_process_f32")
         return out
 
     # -- post-process -----------------------------------------------------------------------

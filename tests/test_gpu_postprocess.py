@@ -1,0 +1,81 @@
+"""GPU parity of the post-process kernels (through s2sr_postprocess_u8) against the numpy
+oracle: every stage is integer / fixed-point or a fixed sequence of float32 operations, so
+the bar is BIT-EXACT."""
+import numpy as np
+import pytest
+
+from oracle import postprocess_ref as pp
+from s2sr import native
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = native.Engine(num_block=1)
+    yield e
+    e.close()
+
+
+def _imgs():
+    rng = np.random.default_rng(4)
+    out = []
+    # smooth green-dominant field-like image (exercises the hue 36..84 branch), cf. SURVEY 8d
+    base = rng.integers(0, 256, (96, 128, 3)).astype(np.float32)
+    k = np.ones((5, 5), np.float32) / 25
+    sm = np.stack([np.convolve(base[..., c].ravel(), np.ones(25) / 25, "same").reshape(96, 128) for c in range(3)], -1)
+    g = np.clip(sm * np.array([0.5, 1.0, 0.45]) + np.array([20, 60, 10]), 0, 255).astype(np.uint8)
+    out.append(("green", g))
+    out.append(("noise", rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)))
+    out.append(("ragged", rng.integers(0, 256, (67, 101, 3), dtype=np.uint8)))      # CLAHE pads both dims
+    out.append(("half_ragged", rng.integers(0, 256, (64, 100, 3), dtype=np.uint8)))  # one dim divisible
+    out.append(("flat", np.full((40, 48, 3), 100, np.uint8)))
+    grad = np.zeros((128, 256, 3), np.uint8)
+    grad[..., 0] = np.arange(256)[None, :]
+    grad[..., 1] = (np.arange(128) * 2)[:, None]
+    grad[..., 2] = 255 - np.arange(256)[None, :]
+    out.append(("gradient", grad))
+    return out
+
+
+@pytest.mark.parametrize("name,img", _imgs())
+def test_stages_bit_exact(eng, name, img):
+    P = native.PPParams
+    cases = {
+        "clahe": (P(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.2, 1), lambda x: pp.local_contrast(x, 2.5, 8)),
+        "clahe3": (P(3.0, 8, 1.0, 1.0, 0.0, 35, 85, 1.0, 1), lambda x: pp.local_contrast(x, 3.0, 8)),
+        "unsharp_wow": (P(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.2, 2), lambda x: pp.unsharp(x, 1.2, 1.4, -0.4)),
+        "unsharp_farm": (P(2.5, 8, 1.5, 2.2, -1.2, 35, 85, 1.3, 2), lambda x: pp.unsharp(x, 1.5, 2.2, -1.2)),
+        "veg12": (P(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.2, 4), lambda x: pp.vegetation(x, 1.2)),
+        "veg13": (P(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.3, 4), lambda x: pp.vegetation(x, 1.3)),
+        "wow": (native.pp_wow(), pp.enhance_for_crops),
+        "farm": (native.pp_farm(), pp.farm_postprocess),
+    }
+    for cname, (prm, fn) in cases.items():
+        got = eng.postprocess_u8(img, prm)
+        exp = fn(img)
+        d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+        assert d.max() == 0, f"{name}/{cname}: {int((d > 0).sum())} bytes differ, max {int(d.max())}"
+
+
+def test_all_hsv_and_lab_values(eng):
+    """Every (hue, sat) pair at two values, and a dense RGB lattice: exhaustive over the LUT domains."""
+    h, s = np.meshgrid(np.arange(180), np.arange(256), indexing="ij")
+    for v in (255, 131):
+        hsv = np.stack([h, s, np.full_like(h, v)], -1).astype(np.uint8)
+        rgb = pp.hsv2rgb_u8(hsv)
+        for gain, prm in ((1.2, native.pp_wow()), (1.3, native.pp_farm())):
+            prm.stages = 4
+            assert np.array_equal(eng.postprocess_u8(rgb, prm), pp.vegetation(rgb, gain))
+    r, g, b = np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5), indexing="ij")
+    lat = np.stack([r, g, b], -1).reshape(52 * 4, 13 * 52, 3).astype(np.uint8)
+    prm = native.pp_wow()
+    prm.stages = 1
+    assert np.array_equal(eng.postprocess_u8(lat, prm), pp.local_contrast(lat, 2.5, 8))
+
+
+def test_wow_on_sr_sized_image(eng):
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    img[..., 1] = np.maximum(img[..., 1], 90)
+    assert np.array_equal(eng.postprocess_u8(img, native.pp_wow()), pp.enhance_for_crops(img))

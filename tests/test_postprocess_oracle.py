@@ -1,0 +1,75 @@
+"""CPU checks of the post-process oracle (oracle/postprocess_ref.py): published 8-bit OpenCV
+known answers and structural properties.  (Parity of this stage is UNPINNED: no cv2 here.)"""
+import numpy as np
+
+from oracle import postprocess_ref as pp
+
+
+def test_known_answers_lab_hsv():
+    cols = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [255, 255, 0]]], np.uint8)
+    lab = pp.rgb2lab_u8(cols)[0].tolist()
+    # cv2.cvtColor(..., COLOR_RGB2LAB) on uint8 primaries (widely published values)
+    assert lab[:5] == [[136, 208, 195], [224, 42, 211], [82, 207, 20], [255, 128, 128], [0, 128, 128]]
+    hsv = pp.rgb2hsv_u8(cols)[0].tolist()
+    assert hsv == [[0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 255], [0, 0, 0], [30, 255, 255]]
+    assert np.array_equal(pp.hsv2rgb_u8(pp.rgb2hsv_u8(cols)), cols)
+
+
+def test_gray_axis_roundtrip_and_identity_properties():
+    g = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    lab = pp.rgb2lab_u8(g)
+    assert np.all(lab[..., 1] == 128) and np.all(lab[..., 2] == 128)
+    assert np.all(np.diff(lab[0, :, 0].astype(int)) >= 0)            # L monotone in gray level
+    assert np.abs(pp.lab2rgb_u8(lab).astype(int) - g).max() <= 1
+    assert np.array_equal(pp.hsv2rgb_u8(pp.rgb2hsv_u8(g)), g)        # S == 0 path is exact
+
+
+def test_gaussian_kernel_and_blur():
+    for sigma, n in ((1.2, 9), (1.5, 11), (1.0, 7)):
+        t = pp.gaussian_kernel_q8(sigma)
+        assert len(t) == n and t.sum() == 256 and np.array_equal(t, t[::-1])
+    flat = np.full((20, 30, 3), 77, np.uint8)
+    assert np.array_equal(pp.gaussian_blur_u8(flat, 1.2), flat)
+    assert np.array_equal(pp.unsharp(flat, 1.2, 1.4, -0.4), flat)
+
+
+def test_vegetation_mask_bounds_and_trunc():
+    # one pixel per hue 0..179 at S=100, V=200 -> boost applies to H in 36..84 only
+    hsv = np.zeros((1, 180, 3), np.uint8)
+    hsv[0, :, 0] = np.arange(180)
+    hsv[0, :, 1] = 100
+    hsv[0, :, 2] = 200
+    rgb = pp.hsv2rgb_u8(hsv)
+    back = pp.rgb2hsv_u8(rgb)
+    out = pp.rgb2hsv_u8(pp.vegetation(rgb, 1.2))
+    boosted = out[0, :, 1].astype(int) > back[0, :, 1].astype(int) + 5
+    hh = back[0, :, 0].astype(int)
+    assert not boosted[(hh <= 35) | (hh >= 85)].any()
+    assert boosted[(hh > 36) & (hh < 84)].all()
+    # f32(1.3)*10 is an exact tie that rounds to 13.0 -> astype(uint8) gives 13
+    assert int(np.float32(10) * np.float32(1.3)) == 13
+    assert int(np.clip(np.float32(250) * np.float32(1.2), 0, 255)) == 255
+
+
+def test_clahe_properties():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (64, 96), dtype=np.uint8)
+    out = pp.clahe_u8(img, 2.5, 8)
+    assert out.shape == img.shape and out.dtype == np.uint8
+    # per-pixel LUTs are monotone, so within one interpolation cell order is preserved
+    blk = img[:4, :6].astype(int).ravel()
+    ob = out[:4, :6].astype(int).ravel()
+    i, j = np.argmin(blk), np.argmax(blk)
+    assert ob[i] <= ob[j]
+    # ragged size: both dimensions get padded (odd sizes must not crash)
+    assert pp.clahe_u8(rng.integers(0, 256, (67, 101), dtype=np.uint8), 2.5, 8).shape == (67, 101)
+    assert pp.clahe_u8(rng.integers(0, 256, (64, 101), dtype=np.uint8), 3.0, 8).shape == (64, 101)
+
+
+def test_pipelines_run():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (72, 88, 3), dtype=np.uint8)
+    a = pp.enhance_for_crops(img)
+    b = pp.farm_postprocess(img)
+    assert a.shape == img.shape == b.shape and a.dtype == np.uint8
+    assert not np.array_equal(a, b)
