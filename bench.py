@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SR megapixels/s on batches of 256x256x3 tiles, RRDBNet x4 (23 blocks),
+fp16-MFMA path, one process per GPU (BASELINE.json: metric / configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of 32 synthetic tiles per GPU, inputs and
+outputs resident in HBM: u8 tiles -> pack -> 351 convs -> u8 SR tiles (+ for N>1 the RCCL
+all-gather of the output tiles the north star names).  Weak scaling: every rank has its own 32
+tiles.  Rank 0 prints ONE JSON line.  Weights: seeded synthetic RealESRGAN_x4plus shapes (no
+checkpoints offline), broadcast from rank 0 over RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+for p in (str(REPO / "sentinel2-super-resolution-poc_amd"), str(REPO)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+from s2sr import native  # noqa: E402
+from s2sr.synth import synthetic_tiles  # noqa: E402
+from s2sr.weights import flatten_state_dict, num_params, synthetic_state_dict  # noqa: E402
+
+FLOP_PER_LR_PX = 35_853_696          # SURVEY.md section 8d (23 blocks)
+MFMA_F16_PEAK_TFLOPS = 2500.0        # dense fp16 MFMA, MI355X_MICROARCH.md
+TILE = 256
+BATCH = 32
+NUM_BLOCK = 23
+
+
+def cpu_baseline(seed_tiles: np.ndarray) -> dict:
+    """The oracle (CPU restatement of RealESRGAN.enhance, fp32 torch) timed on this host's
+    cores on a bounded sample of the same workload.  Checker code used as a reported baseline
+    only -- nothing of it is on the product path."""
+    from oracle import rrdbnet_ref as ref
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("S2SR_CPU_THREADS", str(min(avail, 32))))
+    torch.set_num_threads(cores)
+    sd = ref.to_torch_sd(synthetic_state_dict(NUM_BLOCK, seed=0))
+    ref.enhance(seed_tiles[0][:64, :64], sd, NUM_BLOCK)            # warm-up (small)
+    n = 2
+    t0 = time.perf_counter()
+    for i in range(n):
+        ref.enhance(seed_tiles[i], sd, NUM_BLOCK)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(16 * TILE * TILE / 1e6 / dt, 4), "unit": "SR-MP/s", "cores": cores, "kind": "port",
+            "sample": f"{n} tiles of {TILE}x{TILE}x3 through the fp32 oracle (23 blocks) after a 64x64 warm-up; "
+                      f"{dt:.2f} s/tile", "s_per_tile": round(dt, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--group", type=int, default=int(os.environ.get("S2SR_GROUP", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--enhance-crops", action="store_true", help="also run the CLAHE/unsharp/vegetation pass")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+
+    # ---- weights: rank 0 builds the blob, RCCL broadcast over xGMI ----------------------------
+    nparam = num_params(NUM_BLOCK)
+    if rank == 0:
+        blob = torch.from_numpy(flatten_state_dict(synthetic_state_dict(NUM_BLOCK, seed=0), NUM_BLOCK)).to(dev)
+    else:
+        blob = torch.empty(nparam, dtype=torch.float32, device=dev)
+    if dist is not None:
+        dist.broadcast(blob, src=0)
+    eng = native.Engine(num_block=NUM_BLOCK, device=local, group=a.group)
+    eng.load_blob(blob.cpu().numpy())
+    del blob
+
+    # ---- synthetic inputs, resident in HBM before the timed region ------
+    B = a.batch
+    tiles_np = synthetic_tiles(B, TILE, seed=1234 + rank)
+    x = torch.from_numpy(tiles_np).to(dev)
+    y = torch.empty((B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev)
+    y2 = torch.empty_like(y) if a.enhance_crops else None
+    gathered = torch.empty((world * B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+    prm = native.pp_wow()
+
+    def step():
+        eng.forward_batch_u8_dev(x.data_ptr(), B, TILE, TILE, y.data_ptr(), stream)
+        out = y
+        if a.enhance_crops:
+            eng.postprocess_batch_u8_dev(y.data_ptr(), B, 4 * TILE, 4 * TILE, prm, y2.data_ptr(), stream)
+            out = y2
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+
+    # ---- timed region: exactly K steps.  Every 8th launch of each kernel family is bracketed
+    # by a hipEvent pair on the launch stream (sampling keeps the event overhead < 1 %).
+    eng.set_profiling(8)
+    eng.reset_kernel_stats()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = eng.kernel_stats()
+    eng.set_profiling(0)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        tiles_per_s = world * B * a.steps / dt
+        value = tiles_per_s * 16 * TILE * TILE / 1e6
+        # dominant kernel family by device time
+        conv = {k: v for k, v in stats.items() if v["launches"] and v["flops"] > 0}
+        dom = max(conv, key=lambda k: conv[k]["total_ms"])
+        d = conv[dom]
+        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+        rdb_ms = sum(conv[k]["total_ms"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
+        rdb_fl = sum(conv[k]["flops"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
+        traffic = None
+        pmc = REPO / "profiles" / "pmc_summary.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "SR megapixels/sec (whole node) on 256x256 RGB tiles, x4",
+            "value": round(value, 2), "unit": "SR-MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batch={B} tiles of {TILE}x{TILE}x3 per GPU, RRDBNet x4 "
+                                   f"({NUM_BLOCK} blocks) fp16 MFMA, u8 in -> u8 out"
+                                   + (", + enhance_crops post-process" if a.enhance_crops else "")
+                                   + (", + RCCL all-gather of output tiles" if world > 1 else ""),
+                       "tiles_per_s": round(tiles_per_s, 2), "input_MP_per_s": round(value / 16, 3),
+                       "net_TFLOP_per_s_per_gpu": round(tiles_per_s / world * TILE * TILE * FLOP_PER_LR_PX / 1e12, 1),
+                       "group": a.group, "weights": "seeded synthetic RealESRGAN_x4plus shapes (seed 0)"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1),
+                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4),
+                         "traffic": traffic,
+                         "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
+                         "rdb_convs_TFLOP_per_s": round(rdb_fl / (rdb_ms * 1e-3) / 1e12, 1) if rdb_ms else None,
+                         "rdb_convs_frac": round(rdb_fl / (rdb_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if rdb_ms else None,
+                         "families": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
+                                          "TFLOP_per_s": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["total_ms"] else 0,
+                                          "alg_GB_per_s": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else 0}
+                                      for k, v in stats.items() if v["launches"]}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tiles_np)
+        print(json.dumps(line), flush=True)
+    barrier()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,7 +130,9 @@ int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t 
 int  s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
                                    const s2sr_pp_params* prm, void* d_out, void* stream);
 
-/* measurement: HIP-event timing per kernel family on the launch stream */
+/* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;
+ * on = N >= 1: every N-th launch of each family is bracketed by a hipEvent pair (N > 1 keeps
+ * the event overhead out of a timed region; stats then cover the sampled launches only). */
 int  s2sr_set_profiling(s2sr_handle* h, int32_t on);
 int  s2sr_get_kernel_stats(s2sr_handle* h, s2sr_kstat* out, int32_t cap, int32_t* n);
 int  s2sr_reset_kernel_stats(s2sr_handle* h);
@@ -141,6 +143,13 @@ int  s2sr_synchronize(s2sr_handle* h);
 int  s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W,
                      const float* weight, const float* bias, int32_t Cout, int32_t upsample,
                      int32_t act, float* y);
+
+/* diagnostic: time one RDB-shaped conv (cin in {64,96,128,160,192}; cout 32 -> conv1..4 form,
+ * cout 64 -> conv5 form) over N images of HxW, `iters` launches; avg_us = mean launch time from
+ * HIP events.  If trace != NULL, one extra launch of the stamped diagnostic build fills
+ * trace[wg*24 + k] with s_memtime ticks for the first trace_wgs workgroups. */
+int  s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout,
+                           int32_t iters, float* avg_us, uint64_t* trace, int32_t trace_wgs);
 
 #ifdef __cplusplus
 }

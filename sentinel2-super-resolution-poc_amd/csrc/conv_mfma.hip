@@ -21,6 +21,8 @@
 // Activations have a physical zero halo (s2sr_internal.h), so the loader has no bounds checks;
 // nearest-2x upsampling (cnn_super_resolution.py:146-154) is folded into the loader's source
 // address (>>1), the upsampled tensor is never materialised.
+#include <stdlib.h>
+
 #include "s2sr_internal.h"
 
 namespace s2sr {
@@ -56,7 +58,13 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : __fmul_rn(v, 0.2f); }
 
-template <int CT, int NP, int WAVES, int EPI, bool UP>
+#define S2SR_STAMP(k)                                                              \
+    do {                                                                           \
+        if (TRACE && p.trace && tid == 0 && (k) < 24)                              \
+            p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int CT, int NP, int WAVES, int EPI, bool UP, bool TRACE = false>
 __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16_kernel(const ConvParams p) {
     using G = ConvGeom<WAVES, NP, CT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,6 +72,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16_kernel(const ConvParam
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    S2SR_STAMP(0);
 
     // ---- tile decode; blockIdx -> tile is XCD-aware: the 8 XCDs (blockIdx % 8 labels the
     // blocks that share one) each take a contiguous run of tiles, so neighbouring patches
@@ -174,19 +183,25 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16_kernel(const ConvParam
     char* buf0 = smem;
     char* buf1 = smem + G::BUF_BYTES;
     const int nch = p.nchunks;
+    S2SR_STAMP(1);
     stage(0, buf0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    S2SR_STAMP(2);
     for (int c = 0;;) {
         if (c + 1 < nch) stage(c + 1, buf1);
         compute(buf0);
+        S2SR_STAMP(3 + 2 * c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        S2SR_STAMP(4 + 2 * c);
         if (++c >= nch) break;
         if (c + 1 < nch) stage(c + 1, buf0);
         compute(buf1);
+        S2SR_STAMP(3 + 2 * c);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        S2SR_STAMP(4 + 2 * c);
         if (++c >= nch) break;
     }
 
@@ -260,17 +275,23 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16_kernel(const ConvParam
             }
         }
     }
+    S2SR_STAMP(23);
 }
 
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-static constexpr int kWaves = 8, kNP = 2;   // 16 x 32 pixel patch per workgroup
+// Workgroup shapes: 8 waves x 2 rows (16 x 32 px patch, 1 workgroup / CU) or 4 waves x 2 rows
+// (8 x 32 px patch; with one cout tile the LDS footprint is exactly 80 KiB -> 2 workgroups / CU).
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
-template <int CT, int EPI, bool UP>
+template <int CT, int EPI, bool UP, int WAVES, int NP>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
-    using G = ConvGeom<kWaves, kNP, CT>;
-    auto kern = conv3x3_f16_kernel<CT, kNP, kWaves, EPI, UP>;
+    using G = ConvGeom<WAVES, NP, CT>;
+    auto kern = conv3x3_f16_kernel<CT, NP, WAVES, EPI, UP>;
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -281,22 +302,50 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     q.tilesX = (p.W + G::TW - 1) / G::TW;
     q.tilesY = (p.H + G::TH - 1) / G::TH;
     const int grid = q.tilesX * q.tilesY * p.N;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), G::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), G::LDS_BYTES, st, q);
     return hipGetLastError();
+}
+
+hipError_t launch_conv_f16_trace(const ConvParams& p, int ct, hipStream_t st) {
+    if (ct == 1) {
+        using G = ConvGeom<8, 2, 1>;
+        auto kern = conv3x3_f16_kernel<1, 2, 8, EPI_LRELU, false, true>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        ConvParams q = p;
+        q.tilesX = (p.W + G::TW - 1) / G::TW; q.tilesY = (p.H + G::TH - 1) / G::TH;
+        hipLaunchKernelGGL(kern, dim3(q.tilesX * q.tilesY * p.N), dim3(512), G::LDS_BYTES, st, q);
+    } else {
+        using G = ConvGeom<8, 2, 2>;
+        auto kern = conv3x3_f16_kernel<2, 2, 8, EPI_RDB5, false, true>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        ConvParams q = p;
+        q.tilesX = (p.W + G::TW - 1) / G::TW; q.tilesY = (p.H + G::TH - 1) / G::TH;
+        hipLaunchKernelGGL(kern, dim3(q.tilesX * q.tilesY * p.N), dim3(512), G::LDS_BYTES, st, q);
+    }
+    return hipGetLastError();
+}
+
+template <int CT, int EPI, bool UP>
+static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
+    static const int small_ct1 = env_int("S2SR_CT1_WAVES", 8);
+    if (CT == 1 && EPI == EPI_LRELU && !UP && small_ct1 == 4) return launch_t<CT, EPI, UP, 4, 2>(p, st);
+    return launch_t<CT, EPI, UP, 8, 2>(p, st);
 }
 
 hipError_t launch_conv_f16(const ConvParams& p, int ct, int epi, bool up, hipStream_t st) {
     if (ct == 1) {
-        if (epi == EPI_LRELU && !up) return launch_t<1, EPI_LRELU, false>(p, st);
-        if (epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false>(p, st);
-        if (epi == EPI_DEBUG) return up ? launch_t<1, EPI_DEBUG, true>(p, st) : launch_t<1, EPI_DEBUG, false>(p, st);
+        if (epi == EPI_LRELU && !up) return launch_w<1, EPI_LRELU, false>(p, st);
+        if (epi == EPI_LAST && !up) return launch_w<1, EPI_LAST, false>(p, st);
+        if (epi == EPI_DEBUG) return up ? launch_w<1, EPI_DEBUG, true>(p, st) : launch_w<1, EPI_DEBUG, false>(p, st);
     } else if (ct == 2) {
-        if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true>(p, st) : launch_t<2, EPI_LRELU, false>(p, st);
-        if (epi == EPI_RDB5 && !up) return launch_t<2, EPI_RDB5, false>(p, st);
-        if (epi == EPI_RDB5_RRDB && !up) return launch_t<2, EPI_RDB5_RRDB, false>(p, st);
-        if (epi == EPI_FIRST && !up) return launch_t<2, EPI_FIRST, false>(p, st);
-        if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false>(p, st);
-        if (epi == EPI_DEBUG) return up ? launch_t<2, EPI_DEBUG, true>(p, st) : launch_t<2, EPI_DEBUG, false>(p, st);
+        if (epi == EPI_LRELU) return up ? launch_w<2, EPI_LRELU, true>(p, st) : launch_w<2, EPI_LRELU, false>(p, st);
+        if (epi == EPI_RDB5 && !up) return launch_w<2, EPI_RDB5, false>(p, st);
+        if (epi == EPI_RDB5_RRDB && !up) return launch_w<2, EPI_RDB5_RRDB, false>(p, st);
+        if (epi == EPI_FIRST && !up) return launch_w<2, EPI_FIRST, false>(p, st);
+        if (epi == EPI_BODY && !up) return launch_w<2, EPI_BODY, false>(p, st);
+        if (epi == EPI_DEBUG) return up ? launch_w<2, EPI_DEBUG, true>(p, st) : launch_w<2, EPI_DEBUG, false>(p, st);
     }
     return hipErrorInvalidValue;
 }

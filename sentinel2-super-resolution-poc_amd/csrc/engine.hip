@@ -21,9 +21,22 @@ thread_local std::string g_create_error;
 
 struct ConvW {
     int cin = 0, cout = 0, nchunks = 0, ct = 0;
-    void* d_wpack = nullptr;
+    void* d_wpack = nullptr;        // v1 layout
+    void* d_wpack_ring = nullptr;   // v2 (ring) layout
     float* d_bias = nullptr;
 };
+
+int kernel_version() {
+    static const int v = [] { const char* e = getenv("S2SR_KERNEL"); return e ? atoi(e) : 2; }();
+    return v;
+}
+
+hipError_t launch_conv_any(const ConvParams& p, const void* w1, const void* w2, int ct, int epi, bool up, hipStream_t st) {
+    ConvParams q = p;
+    if (kernel_version() == 1) { q.wpack = w1; return launch_conv_f16(q, ct, epi, up, st); }
+    q.wpack = w2;
+    return launch_conv_f16_ring(q, ct, epi, up, st);
+}
 
 // kernel families for the HIP-event statistics
 enum Fam { F_PACK, F_FIRST, F_RDB14, F_RDB5, F_BODY, F_UP, F_HR, F_LAST, F_POST, F_MISC, F_COUNT };
@@ -62,7 +75,8 @@ struct s2sr_handle {
     void* d_scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
     // profiling
-    bool prof = false;
+    int prof = 0;                 // 0 off, N>=1: bracket every N-th launch of each family with events
+    int64_t fam_count[16] = {0};
     std::vector<EvRec> evs;
     std::vector<hipEvent_t> ev_pool;
     s2sr_kstat stats[F_COUNT];
@@ -163,7 +177,9 @@ struct Scope {   // brackets one launch with events when profiling is on
     hipStream_t st;
     EvRec r;
     bool on;
-    Scope(s2sr_handle* h_, hipStream_t st_, int fam, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+    Scope(s2sr_handle* h_, hipStream_t st_, int fam, double flops, double bytes) : h(h_), st(st_), on(false) {
+        if (h->prof <= 0) return;
+        on = (h->fam_count[fam]++ % h->prof) == 0;
         if (!on) return;
         r.fam = fam; r.flops = flops; r.bytes = bytes;
         r.e0 = get_event(h); r.e1 = get_event(h);
@@ -193,7 +209,6 @@ int collect_events(s2sr_handle* h) {
 
 // one conv launch of the fp16 path
 int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParams p, int epi, bool up) {
-    p.wpack = cw.d_wpack;
     p.bias = cw.d_bias;
     p.nchunks = cw.nchunks;
     if (p.split <= 0 || p.split > p.nchunks) p.split = p.nchunks;
@@ -208,7 +223,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 12.0;
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
-    HIPCHK(h, launch_conv_f16(p, cw.ct, epi, up, st));
+    HIPCHK(h, launch_conv_any(p, cw.d_wpack, cw.d_wpack_ring, cw.ct, epi, up, st));
     return S2SR_OK;
 }
 
@@ -377,6 +392,7 @@ void s2sr_destroy(s2sr_handle* h) {
     hipDeviceSynchronize();
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
+        if (c.d_wpack_ring) hipFree(c.d_wpack_ring);
         if (c.d_bias) hipFree(c.d_bias);
     }
     if (h->ws.base) hipFree(h->ws.base);
@@ -402,6 +418,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
+        if (c.d_wpack_ring) hipFree(c.d_wpack_ring);
         if (c.d_bias) hipFree(c.d_bias);
     }
     h->convs.clear();
@@ -414,9 +431,12 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         const size_t wb = conv_wpack_bytes(s.cin, s.cout);
         tmp.resize(wb);
         pack_conv_weights(pw, s.cin, s.cout, 1.0f, tmp.data());
-        pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
         HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
+        pack_conv_weights_ring(pw, s.cin, s.cout, 1.0f, tmp.data());
+        HIPCHK(h, hipMalloc(&cw.d_wpack_ring, wb));
+        HIPCHK(h, hipMemcpy(cw.d_wpack_ring, tmp.data(), wb, hipMemcpyHostToDevice));
+        pw += (size_t)s.cin * s.cout * 9;
         float bias[64] = {0};
         memcpy(bias, pw, sizeof(float) * s.cout);
         pw += s.cout;
@@ -626,7 +646,8 @@ int s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W
 int s2sr_set_profiling(s2sr_handle* h, int32_t on) {
     if (!h) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    h->prof = on != 0;
+    h->prof = on < 0 ? 0 : on;
+    for (int i = 0; i < 16; ++i) h->fam_count[i] = 0;
     return S2SR_OK;
 }
 
@@ -678,7 +699,8 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, hipMalloc((void**)&d_w, wb));
     HIPCHK(h, hipMalloc((void**)&d_b, 64 * 4));
     std::vector<char> wp(wb);
-    pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
+    if (kernel_version() == 1) pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
+    else pack_conv_weights_ring(weight, Cin, Cout, 1.0f, wp.data());
     float bb[64] = {0};
     memcpy(bb, bias, Cout * sizeof(float));
     HIPCHK(h, hipMemsetAsync(d_plane, 0, plane_b, st));
@@ -690,10 +712,78 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     p.src0 = d_plane; p.src1 = d_plane; p.rec0 = p.rec1 = (uint32_t)Cp * 2; p.nchunks = Cp / 32; p.split = p.nchunks;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = OHh; p.W = OWw; p.Hp = Hp; p.Wp = Wp; p.sHp = sHp; p.sWp = sWp;
     p.out_f32 = d_y; p.cout = Cout; p.act = act;
-    HIPCHK(h, launch_conv_f16(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
+    HIPCHK(h, launch_conv_any(p, d_w, d_w, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
+    return S2SR_OK;
+}
+
+int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t iters,
+                          float* avg_us, uint64_t* trace, int32_t trace_wgs) {
+    if (!h || !avg_us || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || cin < 64 || cin > 192 || cin % 32 ||
+        (cout != 32 && cout != 64))
+        return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const int Hp = padded(H), Wp = padded(W);
+    const size_t px = (size_t)N * Hp * Wp;
+    char *X = nullptr, *X2 = nullptr, *Gd = nullptr, *d_w = nullptr;
+    float *T = nullptr, *d_b = nullptr;
+    unsigned long long* d_tr = nullptr;
+    const size_t wb = conv_wpack_bytes(cin, cout);
+    HIPCHK(h, hipMalloc((void**)&X, px * 128));
+    HIPCHK(h, hipMalloc((void**)&X2, px * 128));
+    HIPCHK(h, hipMalloc((void**)&Gd, px * 256));
+    HIPCHK(h, hipMalloc((void**)&T, px * 256));
+    HIPCHK(h, hipMalloc((void**)&d_w, wb));
+    HIPCHK(h, hipMalloc((void**)&d_b, 256));
+    // pseudo-random fp16 bit patterns (finite, |v| < 2): 0x3c.. / 0xbb.. bytes
+    std::vector<unsigned char> pat(px * 256);
+    unsigned s = 12345u;
+    for (size_t i = 0; i < pat.size(); i += 2) {
+        s = s * 1664525u + 1013904223u;
+        pat[i] = (unsigned char)(s >> 24);
+        pat[i + 1] = (unsigned char)(((s >> 16) & 0x80) | 0x30 | ((s >> 8) & 0x0b));
+    }
+    HIPCHK(h, hipMemcpy(Gd, pat.data(), px * 256, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(X, pat.data(), px * 128, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_w, pat.data(), wb < pat.size() ? wb : pat.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(T, 0, px * 256));
+    HIPCHK(h, hipMemset(d_b, 0, 256));
+    ConvParams p{};
+    p.src0 = X; p.rec0 = 128; p.src1 = Gd; p.rec1 = 256; p.split = 2; p.nchunks = cin / 32;
+    p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
+    p.T = T; p.R = T; p.F = T;
+    int epi;
+    if (cout == 32) { p.dst = Gd; p.dst_rec = 256; p.dst_coff = 192; epi = EPI_LRELU; }
+    else { p.dst = X2; p.dst_rec = 128; p.dst_coff = 0; epi = EPI_RDB5; }
+    const int ct = cout / 32;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv_any(p, d_w, d_w, ct, epi, false, st));
+    HIPCHK(h, hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv_any(p, d_w, d_w, ct, epi, false, st));
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.0f / iters;
+    if (trace && trace_wgs > 0) {
+        const int nwg = ((W + 31) / 32) * ((H + 15) / 16) * N;
+        HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
+        HIPCHK(h, hipMemset(d_tr, 0, (size_t)nwg * 24 * 8));
+        p.trace = d_tr;
+        HIPCHK(h, launch_conv_f16_trace(p, ct, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        const int nw = trace_wgs < nwg ? trace_wgs : nwg;
+        HIPCHK(h, hipMemcpy(trace, d_tr, (size_t)nw * 24 * 8, hipMemcpyDeviceToHost));
+        hipFree(d_tr);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(X); hipFree(X2); hipFree(Gd); hipFree(T); hipFree(d_w); hipFree(d_b);
     return S2SR_OK;
 }
 

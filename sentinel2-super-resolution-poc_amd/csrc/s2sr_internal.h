@@ -52,10 +52,15 @@ struct ConvParams {
     int32_t cout;            // real output channels (EPI_LAST: 3; EPI_DEBUG: Cout)
     int32_t act;             // EPI_DEBUG: apply lrelu
     float in_scale;          // EPI_FIRST: 1/255 (inputs are fed as exact integers 0..255)
+    unsigned long long* trace;   // diagnostic builds only: s_memtime stamps, 24 per workgroup
 };
 
 // conv kernel launchers (conv_mfma.hip).  ct = ceil(Cout/32) in {1,2}.
 hipError_t launch_conv_f16(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
+hipError_t launch_conv_f16_trace(const ConvParams& p, int ct, hipStream_t st);   // diagnostic build with stamps
+// version 2 (conv_ring.hip): persistent workgroups + LDS ring; its own weight layout
+hipError_t launch_conv_f16_ring(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
+void pack_conv_weights_ring(const float* w, int cin, int cout, float wscale, void* dst_host);
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order, zero padded to 32-multiples
 void pack_conv_weights(const float* w, int cin, int cout, float wscale, void* dst_host);

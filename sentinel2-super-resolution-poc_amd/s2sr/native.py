@@ -81,6 +81,7 @@ _PROTOS = {
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
+    "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -218,8 +219,9 @@ class Engine:
                                                             stream or None), "s2sr_postprocess_batch_u8_dev")
 
     # -- measurement ------------------------------------------------------------------------
-    def set_profiling(self, on: bool):
-        self._check(self._lib.s2sr_set_profiling(self._h, int(on)), "s2sr_set_profiling")
+    def set_profiling(self, every: int):
+        """0/False: off; N>=1: HIP-event pair around every N-th launch of each kernel family."""
+        self._check(self._lib.s2sr_set_profiling(self._h, int(every)), "s2sr_set_profiling")
 
     def reset_kernel_stats(self):
         self._check(self._lib.s2sr_reset_kernel_stats(self._h), "s2sr_reset_kernel_stats")
@@ -249,6 +251,18 @@ class Engine:
         self._check(self._lib.s2sr_debug_conv(self._h, _ptr(x), N, cin, H, W, _ptr(weight), _ptr(bias), cout,
                                               int(upsample), int(act), _ptr(y)), "s2sr_debug_conv")
         return y
+
+
+def _bench_conv(self, N, H, W, cin, cout, iters=20, trace_wgs=0):
+    """Diagnostic: (avg launch us, trace[wgs,24] of s_memtime ticks or None)."""
+    us = C.c_float(0)
+    tr = np.zeros((max(trace_wgs, 1), 24), dtype=np.uint64)
+    self._check(self._lib.s2sr_debug_bench_conv(self._h, N, H, W, cin, cout, iters, C.byref(us),
+                                                _ptr(tr) if trace_wgs else None, trace_wgs), "s2sr_debug_bench_conv")
+    return float(us.value), (tr if trace_wgs else None)
+
+
+Engine.bench_conv = _bench_conv
 
 
 def device_count() -> int:
