@@ -1,0 +1,519 @@
+// 3x3 / stride 1 / zero-pad 1 convolution as an im2col-free implicit GEMM on the gfx950 matrix
+// cores: the kernel behind every conv of RRDBNet.forward
+// (reference server/app/cnn_super_resolution.py:85-91,103-107,140-158).
+//
+// GEMM orientation:  D[Cout x pixels] = Wt[Cout x K] * X[K x pixels],  K = 9 taps x Cin.
+//   v_mfma_f32_32x32x16_f16:  A = weights  (lane = cout + 32*(k/8)),
+//                             B = activations (lane = pixel + 32*(k/8)),
+//                             D: lane = pixel column, 16 registers = 16 couts
+//   so a lane ends up owning 16 output channels of ONE pixel: bias, LeakyReLU, the x0.2
+//   residual adds of RDB / RRDB and the stores are lane-local; one v_permlane32_swap per
+//   dword pairs the two half-waves into 16-byte stores.
+//
+// Schedule (measured choices, see DESIGN.md "kernel history"):
+//   * PERSISTENT workgroups, one per CU; each walks a list of 16x32-pixel output patches.  The
+//     (patch, 16-channel input block) pairs form one stream of pipeline stages, so the loads of
+//     the next patch are in flight while the current one finishes and runs its epilogue.
+//   * A stage = one slab plane ((TH+2) x 34 px x 16 ch, 32 B per pixel, 16-B halves XOR-swizzled
+//     with bit 3 of the pixel index: every ds_read_b128 of a B fragment is conflict free) plus
+//     that block's weights in A-fragment order (9 x CT KiB).  Both arrive by LDS-DMA
+//     (global_load_lds_dwordx4) into an R-deep LDS ring: R-2 stages stay in flight behind a
+//     COUNTED s_waitcnt vmcnt(N) and a raw s_barrier; vmcnt(0) appears only at the tail.
+//     Every wave issues the same number of DMA instructions per stage (padding slots re-load
+//     the last piece) so the count is exact.  The DMA and the residual loads are inline asm:
+//     any load hipcc can see inside the ring loop makes it protect register reuse with
+//     vmcnt(0), which drains the ring every stage.
+//   * Activations are "blocked-16" in HBM (s2sr_internal.h): a slab row is 1088 contiguous
+//     bytes, each DMA instruction fetches 8 whole cache lines; the zero halo removes all bounds
+//     checks; nearest-2x upsampling (cnn_super_resolution.py:146-154) is folded into the
+//     loader's source offsets (>>1) and never materialised.
+//   * Inside a stage the 9 A fragments stay in registers and every B fragment (slab row s,
+//     column shift dx) is read ONCE and used for all kernel rows dy with 0 <= s-dy < NP.
+#include <stdlib.h>
+
+#include "s2sr_internal.h"
+
+namespace s2sr {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int WAVES_, int NP_, int CT_, int R_>
+struct Geom {
+    static constexpr int WAVES = WAVES_, NP = NP_, CT = CT_, R = R_;
+    static constexpr int TH = WAVES * NP, TW = 32;
+    static constexpr int SW = TW + 2, SH = TH + 2, SPX = SH * SW;
+    static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
+    static constexpr int PI = PLANE / 1024;            // slab LDS-DMA instructions per stage
+    static constexpr int WI = 9 * CT;                  // weight LDS-DMA instructions per stage
+    static constexpr int NSTI = PI + WI;
+    static constexpr int PW = (NSTI + WAVES - 1) / WAVES;   // DMA instructions per wave per stage
+    static constexpr int STAGE_BYTES = NSTI * 1024;
+    static constexpr int BIAS_OFF = R * STAGE_BYTES;
+    static constexpr int LDS_BYTES = BIAS_OFF + 256;
+    static constexpr int NBSTEP = 3 * (NP + 2);        // B fragments read per stage
+};
+
+// a wave-uniform pointer made PROVABLY uniform for an "s" asm operand
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {
+    const uint64_t v = (uint64_t)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
+// LDS-DMA, 16 B per lane: LDS[lds_addr + lane*16] <- global[base + voff].  M0 is written in the
+// statement that uses it and restored; s_nop 4 covers SGPR operands that come straight from
+// v_readfirstlane.
+__device__ __forceinline__ void glds16(const char* base_, uint32_t voff, uint32_t lds_addr_) {
+    const char* base = uniform_ptr(base_);
+    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_addr_);
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_addr)
+        : "memory");
+}
+
+// 16-B global load hidden from hipcc's waitcnt bookkeeping; valid only after an explicit
+// s_waitcnt vmcnt(0) (asm) that the caller places before the first use.
+__device__ __forceinline__ f32x4 asm_load16(const float* addr) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : __fmul_rn(v, 0.2f); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    // counted wait for this wave's own LDS-DMA, then the workgroup barrier: past it, every
+    // wave's pieces of the awaited stage are in LDS.  One statement, memory clobber: no LDS
+    // read can be scheduled above it.
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+#define S2SR_STAMP(k)                                                              \
+    do {                                                                           \
+        if (TRACE && p.trace && tid == 0 && (k) < 24)                              \
+            p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false>
+__global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
+    using G = Geom<WAVES, NP, CT, R>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pcol = lane & 31, hh = lane >> 5;
+    S2SR_STAMP(0);
+
+    // ---- my patches.  Round `it` of the grid covers tiles [it*nwg, (it+1)*nwg); inside a round
+    // the workgroups that share an XCD (same blockIdx % 8) take one contiguous run of tiles, so
+    // neighbouring patches (shared halos) meet in one XCD's L2.
+    const int nwg = gridDim.x;   // multiple of 8 (host)
+    const int slot_in_round = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+    const int tpi = p.tilesX * p.tilesY;
+    const int ntiles = tpi * p.N;
+    const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;   // >= 0
+    const int NS = p.nstage;                                         // stages per patch
+    const int S = my_tiles * NS;
+    const uint32_t sblk = (uint32_t)p.sHp * p.sWp * 32;              // bytes between source blocks
+    const size_t oblk = (size_t)p.Hp * p.Wp * 32;                    // bytes between output blocks
+
+    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = (EPI == EPI_FIRST) ? 0.f : p.bias[tid];
+
+    // ---- per-lane source offsets of this wave's PW DMA slots (patch independent)
+    uint32_t loff[G::PW];
+#pragma unroll
+    for (int s = 0; s < G::PW; ++s) {
+        int j = wave + s * WAVES;
+        if (j > G::NSTI - 1) j = G::NSTI - 1;
+        loff[s] = 0;
+        if (j < G::PI) {
+            const int i = j * 64 + lane;    // 16-B piece of the slab plane
+            int q = i >> 1;
+            if (q >= G::SPX) q = 0;         // tail pieces land in the plane's pad
+            const int h2 = (i & 1) ^ ((q >> 3) & 1);
+            const int ry = q / G::SW, rx = q - ry * G::SW;
+            const int ly = UP ? ((ry - 1) >> 1) + 1 : ry;   // offset from the patch's source origin
+            const int lx = UP ? ((rx - 1) >> 1) + 1 : rx;
+            loff[s] = (uint32_t)((ly * p.sWp + lx) * 32 + h2 * 16);
+        } else {
+            loff[s] = (uint32_t)((j - G::PI) * 1024 + lane * 16);
+        }
+    }
+
+    // ---- issue cursor: (tile iteration, stage in patch) + uniform base of its patch
+    int it_i = 0, st_i = 0;
+    const char* pbase = nullptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    // ---- B-fragment addresses inside a slab plane: slab row s (relative to the wave), shift dx
+    uint32_t baddr[NP + 2][3];
+#pragma unroll
+    for (int s = 0; s < NP + 2; ++s)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int q = (wave * NP + s) * G::SW + pcol + dx;
+            baddr[s][dx] = (uint32_t)(q * 32 + 16 * (hh ^ ((q >> 3) & 1)));
+        }
+    const uint32_t aaddr = G::PLANE + lane * 16;
+
+    f32x16 acc[CT][NP];
+    auto init_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            f32x16 b;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *(const f32x4*)(smem + G::BIAS_OFF + (ct * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[4 * g + i] = v[i];
+            }
+#pragma unroll
+            for (int np = 0; np < NP; ++np) acc[ct][np] = b;
+        }
+    };
+
+    // One stage.  `do_issue` (workgroup-uniform): also issue the DMA of the stage R-1 ahead into
+    // LDS slot `sl_off`, one instruction per B step, between the MFMAs.
+    auto stage_body = [&](const char* buf, bool do_issue, uint32_t sl_off) __attribute__((always_inline)) {
+        const char* sb = nullptr;
+        const char* wb = nullptr;
+        if (do_issue) {
+            if (st_i == 0) {
+                const int tile = it_i * nwg + slot_in_round;
+                const int n = tile / tpi;
+                const int trem = tile - n * tpi;
+                const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+                const int y0 = ty * G::TH, x0 = tx * G::TW;
+                const size_t opix = UP ? (size_t)(y0 >> 1) * p.sWp + (x0 >> 1) : (size_t)y0 * p.sWp + x0;
+                pbase = p.src + (size_t)n * p.src_img + opix * 32;
+            }
+            sb = pbase + (size_t)st_i * sblk;
+            wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
+            if (++st_i == NS) { st_i = 0; ++it_i; }
+        }
+        f16x8 a[9][CT];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[t][ct] = *(const f16x8*)(buf + aaddr + (t * CT + ct) * 1024);
+        f16x8 b[2];
+        b[0] = *(const f16x8*)(buf + baddr[0][0]);
+#pragma unroll
+        for (int step = 0; step < G::NBSTEP; ++step) {
+            const int s = step / 3, dx = step % 3;
+            if (step + 1 < G::NBSTEP) b[(step + 1) & 1] = *(const f16x8*)(buf + baddr[(step + 1) / 3][(step + 1) % 3]);
+            if (do_issue) {
+#pragma unroll
+                for (int sl = 0; sl < G::PW; ++sl) {
+                    if ((sl < G::NBSTEP - 1 ? sl : G::NBSTEP - 1) != step) continue;
+                    int j = wave + sl * WAVES;
+                    if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
+                    const uint32_t dst = lds0 + sl_off + (uint32_t)j * 1024;
+                    glds16(j < G::PI ? sb : wb, loff[sl], dst);
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int np = s - dy;
+                if (np < 0 || np >= NP) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy * 3 + dx][ct], b[step & 1], acc[ct][np], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- epilogue of the patch at tile iteration `it`
+    auto epilogue = [&](int it) __attribute__((always_inline)) {
+        const int tile = it * nwg + slot_in_round;
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+        const int y0 = ty * G::TH, x0 = tx * G::TW;
+        const int x = x0 + pcol;
+        bool ok[NP];
+        size_t opix[NP];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const int y = y0 + wave * NP + np;
+            ok[np] = (y < p.H) && (x < p.W);
+            opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
+        }
+        const size_t tn = (size_t)n * 8 * oblk;   // image offset inside a trunk tensor (bytes)
+        // residual operands: one burst of independent loads (padded tensors make every address
+        // valid, so they are unconditional).  The RRDB form has twice as many; it loads them per
+        // output row to stay inside the register budget of an 8-wave workgroup.
+        f32x4 res0[CT][NP][4], res1[CT][NP][4];
+        auto load_res = [&](int np) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const size_t o = tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16;
+                    res0[ct][np][g] = asm_load16((const float*)((const char*)p.T + o));
+                    if (EPI == EPI_RDB5_RRDB) res1[ct][np][g] = asm_load16((const float*)((const char*)p.R + o));
+                }
+        };
+        if (EPI == EPI_RDB5) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np) load_res(np);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (EPI == EPI_BODY) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        res0[ct][np][g] = *(const f32x4*)((const char*)p.F + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16);
+        }
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const int y = y0 + wave * NP + np;
+            if (EPI == EPI_RDB5_RRDB) {
+                load_res(np);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                u32x2 hpk[4];   // fp16 x4 per g
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cb = ct * 32 + 8 * g + 4 * hh;   // first of this lane's 4 consecutive couts
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[ct][np][4 * g + i];
+                    const size_t to = tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16;
+                    if (EPI == EPI_LRELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                    } else if (EPI == EPI_RDB5) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res0[ct][np][g][i]);
+                        if (ok[np]) *(f32x4*)((char*)p.T + to) = v;
+                    } else if (EPI == EPI_RDB5_RRDB) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            v[i] = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v[i], 0.2f), res0[ct][np][g][i]), 0.2f),
+                                             res1[ct][np][g][i]);
+                        if (ok[np]) {
+                            *(f32x4*)((char*)p.T + to) = v;
+                            *(f32x4*)((char*)p.R + to) = v;
+                        }
+                    } else if (EPI == EPI_FIRST) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], p.in_scale), p.bias[cb + i]);
+                        if (ok[np]) {
+                            *(f32x4*)((char*)p.T + to) = v;
+                            *(f32x4*)((char*)p.R + to) = v;
+                            *(f32x4*)((char*)p.F + to) = v;
+                        }
+                    } else if (EPI == EPI_BODY) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(res0[ct][np][g][i], v[i]);
+                    }
+                    if (EPI == EPI_LAST || EPI == EPI_DEBUG) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int co = cb + i;
+                            if (co >= p.cout || !ok[np]) continue;
+                            float o = v[i];
+                            if (EPI == EPI_DEBUG && p.act) o = lrelu(o);
+                            if (p.out_f32) p.out_f32[(((size_t)n * p.cout + co) * p.H + y) * p.W + x] = o;
+                            if (EPI == EPI_LAST && p.out_u8) {
+                                // (out*255).clip(0,255).astype(uint8): truncation (cnn_super_resolution.py:232)
+                                const float q = fminf(fmaxf(__fmul_rn(o, 255.0f), 0.f), 255.f);
+                                p.out_u8[(((size_t)n * p.H + y) * p.W + x) * 3 + co] = (uint8_t)(int)q;
+                            }
+                        }
+                    } else {
+                        f16x4 hv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
+                        hpk[g] = __builtin_bit_cast(u32x2, hv);
+                    }
+                }
+                if (EPI != EPI_LAST && EPI != EPI_DEBUG) {
+                    // pair the half-waves: after the swaps lanes 0-31 hold couts 16b..16b+7 and lanes
+                    // 32-63 couts 16b+8..16b+15 of their pixel -> one 16-B store per 16-channel block,
+                    // 1 KiB contiguous per wave-instruction
+#pragma unroll
+                    for (int bk = 0; bk < 2; ++bk) {
+                        u32x2 lo = hpk[2 * bk], hi = hpk[2 * bk + 1];
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+                        u32x4 o;
+                        o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
+                        if (ok[np])
+                            *(u32x4*)(p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16) = o;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- prologue: R-1 stages in flight
+    {
+        // reuse stage_body's issue path without compute: a tiny dedicated loop
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) {
+            if (r < S) {
+                if (st_i == 0) {
+                    const int tile = it_i * nwg + slot_in_round;
+                    const int n = tile / tpi;
+                    const int trem = tile - n * tpi;
+                    const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+                    const int y0 = ty * G::TH, x0 = tx * G::TW;
+                    const size_t opix = UP ? (size_t)(y0 >> 1) * p.sWp + (x0 >> 1) : (size_t)y0 * p.sWp + x0;
+                    pbase = p.src + (size_t)n * p.src_img + opix * 32;
+                }
+                const char* sb = pbase + (size_t)st_i * sblk;
+                const char* wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
+                if (++st_i == NS) { st_i = 0; ++it_i; }
+#pragma unroll
+                for (int sl = 0; sl < G::PW; ++sl) {
+                    int j = wave + sl * WAVES;
+                    if (j > G::NSTI - 1) j = G::NSTI - 1;
+                    glds16(j < G::PI ? sb : wb, loff[sl], lds0 + (uint32_t)(r * G::STAGE_BYTES) + (uint32_t)j * 1024);
+                }
+            }
+        }
+    }
+    __syncthreads();   // bias visible in LDS
+    init_acc();
+    S2SR_STAMP(1);
+
+    int k = 0, it_c = 0, st_c = 0;
+    // one ring revolution per loop trip; every condition below is workgroup-uniform
+    while (k < S) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (k < S) {
+                // stage k must have landed; stages k+1 .. k+R-2 may stay in flight
+                if (k + (R - 2) < S) wait_vm_barrier<G::PW*(R - 2)>();
+                else wait_vm_barrier<0>();
+                S2SR_STAMP(2 + 2 * k);
+                stage_body(smem + r * G::STAGE_BYTES, k + (R - 1) < S, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES));
+                S2SR_STAMP(3 + 2 * k);
+                if (++st_c == NS) {
+                    epilogue(it_c);
+                    init_acc();
+                    st_c = 0;
+                    ++it_c;
+                }
+                ++k;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false>
+static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
+    using G = Geom<WAVES, NP, CT, R>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
+    static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE>;
+    static bool attr_set = false;
+    static int ncu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        attr_set = true;
+    }
+    ConvParams q = p;
+    q.tilesX = (p.W + G::TW - 1) / G::TW;
+    q.tilesY = (p.H + G::TH - 1) / G::TH;
+    const int ntiles = q.tilesX * q.tilesY * p.N;
+    int grid = ncu & ~7;                      // one persistent workgroup per CU
+    if (ntiles < grid) grid = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), G::LDS_BYTES, st, q);
+    return hipGetLastError();
+}
+
+template <int CT, int EPI, bool UP>
+static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
+    constexpr int R = (CT == 1) ? 5 : 4;
+    return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
+}
+
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, hipStream_t st) {
+    if (ct == 1) {
+        if (epi == EPI_LRELU && !up) return launch_w<1, EPI_LRELU, false>(p, st);
+        if (epi == EPI_LAST && !up) return launch_w<1, EPI_LAST, false>(p, st);
+        if (epi == EPI_DEBUG) return up ? launch_w<1, EPI_DEBUG, true>(p, st) : launch_w<1, EPI_DEBUG, false>(p, st);
+    } else if (ct == 2) {
+        if (epi == EPI_LRELU) return up ? launch_w<2, EPI_LRELU, true>(p, st) : launch_w<2, EPI_LRELU, false>(p, st);
+        if (epi == EPI_RDB5 && !up) return launch_w<2, EPI_RDB5, false>(p, st);
+        if (epi == EPI_RDB5_RRDB && !up) return launch_w<2, EPI_RDB5_RRDB, false>(p, st);
+        if (epi == EPI_FIRST && !up) return launch_w<2, EPI_FIRST, false>(p, st);
+        if (epi == EPI_BODY && !up) return launch_w<2, EPI_BODY, false>(p, st);
+        if (epi == EPI_DEBUG) return up ? launch_w<2, EPI_DEBUG, true>(p, st) : launch_w<2, EPI_DEBUG, false>(p, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
+    if (ct == 1) return launch_t<1, EPI_LRELU, false, 8, 2, 5, true>(p, st);
+    return launch_t<2, EPI_RDB5, false, 8, 2, 4, true>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side weight repack.  Layout: [stage = cin/16][tap][ct][lane 0..63][j 0..7] fp16 with
+//   value = W[cout = ct*32 + (lane&31)][cin = stage*16 + 8*(lane>>5) + j][tap/3][tap%3] * wscale
+// -> each stage's weights are 9*CT contiguous KiB, each KiB is exactly what one A-fragment
+// read (ds_read_b128 at lane*16) wants, so the LDS image is a straight copy of global memory.
+// Missing couts / cins are zero.
+// ------------------------------------------------------------------------------------------
+size_t conv_wpack_bytes(int cin, int cout) {
+    const int ns = (cin + 15) / 16, ct = (cout + 31) / 32;
+    return (size_t)ns * 9 * ct * 1024;
+}
+
+void pack_conv_weights(const float* w, int cin, int cout, float wscale, void* dst_host) {
+    const int ns = (cin + 15) / 16, CT = (cout + 31) / 32;
+    f16* d = (f16*)dst_host;
+    for (int s = 0; s < ns; ++s)
+        for (int t = 0; t < 9; ++t)
+            for (int ct = 0; ct < CT; ++ct)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = ct * 32 + (l & 31);
+                        const int ci = s * 16 + 8 * (l >> 5) + j;
+                        float v = 0.f;
+                        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * 9 + t] * wscale;
+                        *d++ = (f16)v;
+                    }
+}
+
+}  // namespace s2sr

@@ -20,23 +20,10 @@ namespace {
 thread_local std::string g_create_error;
 
 struct ConvW {
-    int cin = 0, cout = 0, nchunks = 0, ct = 0;
-    void* d_wpack = nullptr;        // v1 layout
-    void* d_wpack_ring = nullptr;   // v2 (ring) layout
+    int cin = 0, cout = 0, nstage = 0, ct = 0;
+    void* d_wpack = nullptr;
     float* d_bias = nullptr;
 };
-
-int kernel_version() {
-    static const int v = [] { const char* e = getenv("S2SR_KERNEL"); return e ? atoi(e) : 2; }();
-    return v;
-}
-
-hipError_t launch_conv_any(const ConvParams& p, const void* w1, const void* w2, int ct, int epi, bool up, hipStream_t st) {
-    ConvParams q = p;
-    if (kernel_version() == 1) { q.wpack = w1; return launch_conv_f16(q, ct, epi, up, st); }
-    q.wpack = w2;
-    return launch_conv_f16_ring(q, ct, epi, up, st);
-}
 
 // kernel families for the HIP-event statistics
 enum Fam { F_PACK, F_FIRST, F_RDB14, F_RDB5, F_BODY, F_UP, F_HR, F_LAST, F_POST, F_MISC, F_COUNT };
@@ -47,12 +34,15 @@ struct Workspace {
     int G = 0, H = 0, W = 0;   // capacity (images) and logical LR dims
     char* base = nullptr;
     size_t bytes = 0;
-    // LR planes
-    char *P0 = nullptr, *X[2] = {nullptr, nullptr}, *Gd = nullptr, *U0 = nullptr;
-    float *T = nullptr, *R = nullptr, *F = nullptr;
-    // 2x and 4x planes
+    // LR tensors (blocked-16 fp16 / blocked-8 fp32, see s2sr_internal.h)
+    char *P0 = nullptr;                  // input, 1 block
+    char *D[2] = {nullptr, nullptr};     // dense-block tensors, 12 blocks: [x(4) | x1 | x2 | x3 | x4]
+    char *U0 = nullptr;                  // 4 blocks
+    float *T = nullptr, *R = nullptr, *F = nullptr;   // fp32 trunk / RRDB skip / global skip
+    // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
+    size_t blk1 = 0, blk2 = 0, blk4 = 0;   // bytes of one block plane at 1x / 2x / 4x
 };
 
 struct EvRec {
@@ -137,7 +127,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     Workspace& w = h->ws;
     if (w.base && w.G >= G && w.H == H && w.W == W) return S2SR_OK;
     if (w.base) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipDeviceSynchronize());
         HIPCHK(h, hipFree(w.base));
         w = Workspace();
     }
@@ -145,17 +135,19 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     w.Hp = padded(H); w.Wp = padded(W);
     w.Hp2 = padded(2 * H); w.Wp2 = padded(2 * W);
     w.Hp4 = padded(4 * H); w.Wp4 = padded(4 * W);
-    const size_t px1 = (size_t)G * w.Hp * w.Wp, px2 = (size_t)G * w.Hp2 * w.Wp2, px4 = (size_t)G * w.Hp4 * w.Wp4;
+    w.blk1 = (size_t)w.Hp * w.Wp * 32; w.blk2 = (size_t)w.Hp2 * w.Wp2 * 32; w.blk4 = (size_t)w.Hp4 * w.Wp4 * 32;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
-    const size_t oP0 = take(px1 * 64), oX0 = take(px1 * 128), oX1 = take(px1 * 128), oG = take(px1 * 256),
-                 oU0 = take(px1 * 128), oT = take(px1 * 256), oR = take(px1 * 256), oF = take(px1 * 256),
-                 oU1 = take(px2 * 128), oU2 = take(px4 * 128), oU3 = take(px4 * 128);
+    const size_t g = (size_t)G;
+    const size_t oP0 = take(g * w.blk1), oD0 = take(g * 12 * w.blk1), oD1 = take(g * 12 * w.blk1),
+                 oU0 = take(g * 4 * w.blk1), oT = take(g * 8 * w.blk1), oR = take(g * 8 * w.blk1),
+                 oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
+                 oU3 = take(g * 4 * w.blk4);
     w.bytes = off;
     HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
     HIPCHK(h, hipDeviceSynchronize());
-    w.P0 = w.base + oP0; w.X[0] = w.base + oX0; w.X[1] = w.base + oX1; w.Gd = w.base + oG; w.U0 = w.base + oU0;
+    w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.U0 = w.base + oU0;
     w.T = (float*)(w.base + oT); w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
     return S2SR_OK;
@@ -207,12 +199,11 @@ int collect_events(s2sr_handle* h) {
     return S2SR_OK;
 }
 
-// one conv launch of the fp16 path
+// one conv launch
 int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParams p, int epi, bool up) {
+    p.wpack = cw.d_wpack;
     p.bias = cw.d_bias;
-    p.nchunks = cw.nchunks;
-    if (p.split <= 0 || p.split > p.nchunks) p.split = p.nchunks;
-    if (!p.src1) { p.src1 = p.src0; p.rec1 = p.rec0; }
+    p.nstage = cw.nstage;
     const double px = (double)p.N * p.H * p.W;
     const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
     double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
@@ -223,85 +214,78 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 12.0;
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
-    HIPCHK(h, launch_conv_any(p, cw.d_wpack, cw.d_wpack_ring, cw.ct, epi, up, st));
+    HIPCHK(h, launch_conv(p, cw.ct, epi, up, st));
     return S2SR_OK;
 }
 
 // The layer schedule for `n` images already packed into ws.P0.  Exactly the op order of
 // RRDBNet.forward (cnn_super_resolution.py:140-158) with ResidualDenseBlock / RRDB inlined
-// (:85-91, :103-107); the torch.cat of the dense block is the channel layout
-// [X(64) | Gd(128)] read by the loader, never a copy.
+// (:85-91, :103-107).  The torch.cat of the dense block is "the first k blocks of D[cur]",
+// never a copy; conv5 writes the next x into the other dense tensor because neighbouring
+// workgroups still read this one's x as halo.
 int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f32, uint8_t* d_out_u8) {
     Workspace& w = h->ws;
     const int nb = h->cfg.num_block;
     ConvParams b{};
     b.N = n; b.H = H; b.W = W; b.Hp = w.Hp; b.Wp = w.Wp; b.sHp = w.Hp; b.sWp = w.Wp;
     b.T = w.T; b.R = w.R; b.F = w.F;
-    int ci = 0;
-    {   // conv_first: 3 -> 64 (input padded to one 32-channel chunk)
+    int ci = 0, rc;
+    {   // conv_first: 3 -> 64 (input = one 16-channel block)
         ConvParams p = b;
-        p.src0 = w.P0; p.rec0 = 64; p.dst = w.X[0]; p.dst_rec = 128; p.dst_coff = 0; p.in_scale = 1.0f / 255.0f;
-        int rc = run_conv(h, st, F_FIRST, h->convs[ci++], p, EPI_FIRST, false);
-        if (rc) return rc;
+        p.src = w.P0; p.src_img = w.blk1; p.dst = w.D[0]; p.dst_img = 12 * w.blk1; p.in_scale = 1.0f / 255.0f;
+        if ((rc = run_conv(h, st, F_FIRST, h->convs[ci++], p, EPI_FIRST, false))) return rc;
     }
     int cur = 0;
     for (int blk = 0; blk < nb; ++blk)
         for (int r = 0; r < 3; ++r) {
             for (int k = 1; k <= 4; ++k) {
                 ConvParams p = b;
-                p.src0 = w.X[cur]; p.rec0 = 128; p.src1 = w.Gd; p.rec1 = 256; p.split = 2;
-                p.dst = w.Gd; p.dst_rec = 256; p.dst_coff = (uint32_t)(k - 1) * 64;
-                int rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false);
-                if (rc) return rc;
+                p.src = w.D[cur]; p.src_img = 12 * w.blk1;
+                p.dst = w.D[cur] + (size_t)(4 + 2 * (k - 1)) * w.blk1; p.dst_img = 12 * w.blk1;
+                if ((rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false))) return rc;
             }
             ConvParams p = b;
-            p.src0 = w.X[cur]; p.rec0 = 128; p.src1 = w.Gd; p.rec1 = 256; p.split = 2;
-            p.dst = w.X[cur ^ 1]; p.dst_rec = 128; p.dst_coff = 0;
-            int rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false);
-            if (rc) return rc;
+            p.src = w.D[cur]; p.src_img = 12 * w.blk1;
+            p.dst = w.D[cur ^ 1]; p.dst_img = 12 * w.blk1;
+            if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
             cur ^= 1;
         }
     {   // conv_body + global skip
         ConvParams p = b;
-        p.src0 = w.X[cur]; p.rec0 = 128; p.dst = w.U0; p.dst_rec = 128;
-        int rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false);
-        if (rc) return rc;
+        p.src = w.D[cur]; p.src_img = 12 * w.blk1; p.dst = w.U0; p.dst_img = 4 * w.blk1;
+        if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false))) return rc;
     }
     {   // conv_up1 on nearest-2x
         ConvParams p{};
         p.N = n; p.H = 2 * H; p.W = 2 * W; p.Hp = w.Hp2; p.Wp = w.Wp2; p.sHp = w.Hp; p.sWp = w.Wp;
-        p.src0 = w.U0; p.rec0 = 128; p.dst = w.U1; p.dst_rec = 128;
-        int rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true);
-        if (rc) return rc;
+        p.src = w.U0; p.src_img = 4 * w.blk1; p.dst = w.U1; p.dst_img = 4 * w.blk2;
+        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true))) return rc;
     }
     {   // conv_up2 on nearest-2x
         ConvParams p{};
         p.N = n; p.H = 4 * H; p.W = 4 * W; p.Hp = w.Hp4; p.Wp = w.Wp4; p.sHp = w.Hp2; p.sWp = w.Wp2;
-        p.src0 = w.U1; p.rec0 = 128; p.dst = w.U2; p.dst_rec = 128;
-        int rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true);
-        if (rc) return rc;
+        p.src = w.U1; p.src_img = 4 * w.blk2; p.dst = w.U2; p.dst_img = 4 * w.blk4;
+        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true))) return rc;
     }
     ConvParams hr{};
     hr.N = n; hr.H = 4 * H; hr.W = 4 * W; hr.Hp = w.Hp4; hr.Wp = w.Wp4; hr.sHp = w.Hp4; hr.sWp = w.Wp4;
     {
         ConvParams p = hr;
-        p.src0 = w.U2; p.rec0 = 128; p.dst = w.U3; p.dst_rec = 128;
-        int rc = run_conv(h, st, F_HR, h->convs[ci++], p, EPI_LRELU, false);
-        if (rc) return rc;
+        p.src = w.U2; p.src_img = 4 * w.blk4; p.dst = w.U3; p.dst_img = 4 * w.blk4;
+        if ((rc = run_conv(h, st, F_HR, h->convs[ci++], p, EPI_LRELU, false))) return rc;
     }
     {
         ConvParams p = hr;
-        p.src0 = w.U3; p.rec0 = 128; p.out_f32 = d_out_f32; p.out_u8 = d_out_u8; p.cout = 3;
-        int rc = run_conv(h, st, F_LAST, h->convs[ci++], p, EPI_LAST, false);
-        if (rc) return rc;
+        p.src = w.U3; p.src_img = 4 * w.blk4; p.out_f32 = d_out_f32; p.out_u8 = d_out_u8; p.cout = 3;
+        if ((rc = run_conv(h, st, F_LAST, h->convs[ci++], p, EPI_LAST, false))) return rc;
     }
     return S2SR_OK;
 }
 
 int group_size(const s2sr_handle* h, int B, int H, int W) {
     int g = h->cfg.group > 0 ? h->cfg.group : 8;
-    // keep one plane of one group addressable and the workspace modest (<= ~24 GiB)
-    const double per_img = (double)padded(H) * padded(W) * 1472.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
+    // keep the workspace modest (<= ~24 GiB)
+    const double per_img = (double)padded(H) * padded(W) * 1696.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
                            (double)padded(4 * H) * padded(4 * W) * 256.0;
     while (g > 1 && per_img * g > 24.0 * 1024 * 1024 * 1024) --g;
     if (g > B) g = B;
@@ -324,7 +308,7 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
         {
             Scope sc(h, st, F_PACK, 0.0, (double)n * th * tw * (3.0 + 8.0));
             if (d_tiles) HIPCHK(h, launch_pack_u8(d_tiles + (size_t)g0 * th * tw * 3, n, th, tw, w.P0, w.Hp, w.Wp, st));
-            else HIPCHK(h, launch_pack_f32_nchw(d_x_f32 + (size_t)g0 * 3 * th * tw, n, 3, th, tw, 255.0f, w.P0, 32, w.Hp, w.Wp, st));
+            else HIPCHK(h, launch_pack_f32_nchw(d_x_f32 + (size_t)g0 * 3 * th * tw, n, 3, th, tw, 255.0f, w.P0, 1, w.Hp, w.Wp, st));
         }
         rc = run_net(h, st, n, th, tw, d_out_f32 ? d_out_f32 + (size_t)g0 * 3 * opx : nullptr,
                      d_out_u8 ? d_out_u8 + (size_t)g0 * 3 * opx : nullptr);
@@ -392,7 +376,6 @@ void s2sr_destroy(s2sr_handle* h) {
     hipDeviceSynchronize();
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
-        if (c.d_wpack_ring) hipFree(c.d_wpack_ring);
         if (c.d_bias) hipFree(c.d_bias);
     }
     if (h->ws.base) hipFree(h->ws.base);
@@ -418,7 +401,6 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
-        if (c.d_wpack_ring) hipFree(c.d_wpack_ring);
         if (c.d_bias) hipFree(c.d_bias);
     }
     h->convs.clear();
@@ -427,16 +409,13 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     std::vector<char> tmp;
     for (const ConvSpec& s : specs) {
         ConvW cw;
-        cw.cin = s.cin; cw.cout = s.cout; cw.nchunks = (s.cin + 31) / 32; cw.ct = (s.cout + 31) / 32;
+        cw.cin = s.cin; cw.cout = s.cout; cw.nstage = (s.cin + 15) / 16; cw.ct = (s.cout + 31) / 32;
         const size_t wb = conv_wpack_bytes(s.cin, s.cout);
         tmp.resize(wb);
         pack_conv_weights(pw, s.cin, s.cout, 1.0f, tmp.data());
+        pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
         HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
-        pack_conv_weights_ring(pw, s.cin, s.cout, 1.0f, tmp.data());
-        HIPCHK(h, hipMalloc(&cw.d_wpack_ring, wb));
-        HIPCHK(h, hipMemcpy(cw.d_wpack_ring, tmp.data(), wb, hipMemcpyHostToDevice));
-        pw += (size_t)s.cin * s.cout * 9;
         float bias[64] = {0};
         memcpy(bias, pw, sizeof(float) * s.cout);
         pw += s.cout;
@@ -686,10 +665,11 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
-    const int Cp = roundup32(Cin);
+    const int NB = (Cin + 15) / 16;
     const int OHh = upsample ? 2 * H : H, OWw = upsample ? 2 * W : W;
     const int sHp = padded(H), sWp = padded(W), Hp = padded(OHh), Wp = padded(OWw);
-    const size_t plane_b = (size_t)N * sHp * sWp * Cp * 2, xb = (size_t)N * Cin * H * W * 4,
+    const size_t sblk = (size_t)sHp * sWp * 32;
+    const size_t plane_b = (size_t)N * NB * sblk, xb = (size_t)N * Cin * H * W * 4,
                  yb = (size_t)N * Cout * OHh * OWw * 4, wb = conv_wpack_bytes(Cin, Cout);
     char *d_plane = nullptr, *d_w = nullptr;
     float *d_x = nullptr, *d_y = nullptr, *d_b = nullptr;
@@ -699,20 +679,19 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, hipMalloc((void**)&d_w, wb));
     HIPCHK(h, hipMalloc((void**)&d_b, 64 * 4));
     std::vector<char> wp(wb);
-    if (kernel_version() == 1) pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
-    else pack_conv_weights_ring(weight, Cin, Cout, 1.0f, wp.data());
+    pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
     float bb[64] = {0};
     memcpy(bb, bias, Cout * sizeof(float));
     HIPCHK(h, hipMemsetAsync(d_plane, 0, plane_b, st));
     HIPCHK(h, hipMemcpyAsync(d_x, x, xb, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(d_w, wp.data(), wb, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(d_b, bb, sizeof bb, hipMemcpyHostToDevice, st));
-    HIPCHK(h, launch_pack_f32_nchw(d_x, N, Cin, H, W, 1.0f, d_plane, Cp, sHp, sWp, st));
+    HIPCHK(h, launch_pack_f32_nchw(d_x, N, Cin, H, W, 1.0f, d_plane, NB, sHp, sWp, st));
     ConvParams p{};
-    p.src0 = d_plane; p.src1 = d_plane; p.rec0 = p.rec1 = (uint32_t)Cp * 2; p.nchunks = Cp / 32; p.split = p.nchunks;
+    p.src = d_plane; p.src_img = (uint64_t)NB * sblk; p.nstage = NB;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = OHh; p.W = OWw; p.Hp = Hp; p.Wp = Wp; p.sHp = sHp; p.sWp = sWp;
     p.out_f32 = d_y; p.cout = Cout; p.act = act;
-    HIPCHK(h, launch_conv_any(p, d_w, d_w, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
+    HIPCHK(h, launch_conv(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
@@ -721,69 +700,68 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
 
 int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout, int32_t iters,
                           float* avg_us, uint64_t* trace, int32_t trace_wgs) {
-    if (!h || !avg_us || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || cin < 64 || cin > 192 || cin % 32 ||
+    if (!h || !avg_us || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || cin < 16 || cin > 192 || cin % 16 ||
         (cout != 32 && cout != 64))
         return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
     const int Hp = padded(H), Wp = padded(W);
-    const size_t px = (size_t)N * Hp * Wp;
-    char *X = nullptr, *X2 = nullptr, *Gd = nullptr, *d_w = nullptr;
+    const size_t blk = (size_t)Hp * Wp * 32;
+    char *D0 = nullptr, *D1 = nullptr, *d_w = nullptr;
     float *T = nullptr, *d_b = nullptr;
     unsigned long long* d_tr = nullptr;
-    const size_t wb = conv_wpack_bytes(cin, cout);
-    HIPCHK(h, hipMalloc((void**)&X, px * 128));
-    HIPCHK(h, hipMalloc((void**)&X2, px * 128));
-    HIPCHK(h, hipMalloc((void**)&Gd, px * 256));
-    HIPCHK(h, hipMalloc((void**)&T, px * 256));
+    const size_t wb = conv_wpack_bytes(cin, cout), db = (size_t)N * 12 * blk;
+    HIPCHK(h, hipMalloc((void**)&D0, db));
+    HIPCHK(h, hipMalloc((void**)&D1, db));
+    HIPCHK(h, hipMalloc((void**)&T, (size_t)N * 8 * blk));
     HIPCHK(h, hipMalloc((void**)&d_w, wb));
     HIPCHK(h, hipMalloc((void**)&d_b, 256));
-    // pseudo-random fp16 bit patterns (finite, |v| < 2): 0x3c.. / 0xbb.. bytes
-    std::vector<unsigned char> pat(px * 256);
+    // pseudo-random fp16 bit patterns (finite, |v| < 2)
+    std::vector<unsigned char> pat(db > wb ? db : wb);
     unsigned s = 12345u;
-    for (size_t i = 0; i < pat.size(); i += 2) {
+    for (size_t i = 0; i + 1 < pat.size(); i += 2) {
         s = s * 1664525u + 1013904223u;
         pat[i] = (unsigned char)(s >> 24);
         pat[i + 1] = (unsigned char)(((s >> 16) & 0x80) | 0x30 | ((s >> 8) & 0x0b));
     }
-    HIPCHK(h, hipMemcpy(Gd, pat.data(), px * 256, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(X, pat.data(), px * 128, hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemcpy(d_w, pat.data(), wb < pat.size() ? wb : pat.size(), hipMemcpyHostToDevice));
-    HIPCHK(h, hipMemset(T, 0, px * 256));
+    HIPCHK(h, hipMemcpy(D0, pat.data(), db, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_w, pat.data(), wb, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(D1, 0, db));
+    HIPCHK(h, hipMemset(T, 0, (size_t)N * 8 * blk));
     HIPCHK(h, hipMemset(d_b, 0, 256));
     ConvParams p{};
-    p.src0 = X; p.rec0 = 128; p.src1 = Gd; p.rec1 = 256; p.split = 2; p.nchunks = cin / 32;
+    p.src = D0; p.src_img = 12 * blk; p.nstage = cin / 16;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
     p.T = T; p.R = T; p.F = T;
     int epi;
-    if (cout == 32) { p.dst = Gd; p.dst_rec = 256; p.dst_coff = 192; epi = EPI_LRELU; }
-    else { p.dst = X2; p.dst_rec = 128; p.dst_coff = 0; epi = EPI_RDB5; }
+    if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }
+    else { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_RDB5; }
     const int ct = cout / 32;
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv_any(p, d_w, d_w, ct, epi, false, st));
+    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, st));
     HIPCHK(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv_any(p, d_w, d_w, ct, epi, false, st));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, st));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1000.0f / iters;
     if (trace && trace_wgs > 0) {
-        const int nwg = ((W + 31) / 32) * ((H + 15) / 16) * N;
+        const int nwg = 256;
         HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
         HIPCHK(h, hipMemset(d_tr, 0, (size_t)nwg * 24 * 8));
         p.trace = d_tr;
-        HIPCHK(h, launch_conv_f16_trace(p, ct, st));
+        HIPCHK(h, launch_conv_trace(p, ct, st));
         HIPCHK(h, hipStreamSynchronize(st));
         const int nw = trace_wgs < nwg ? trace_wgs : nwg;
         HIPCHK(h, hipMemcpy(trace, d_tr, (size_t)nw * 24 * 8, hipMemcpyDeviceToHost));
         hipFree(d_tr);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(X); hipFree(X2); hipFree(Gd); hipFree(T); hipFree(d_w); hipFree(d_b);
+    hipFree(D0); hipFree(D1); hipFree(T); hipFree(d_w); hipFree(d_b);
     return S2SR_OK;
 }
 

@@ -1,6 +1,6 @@
 // Data-movement kernels around the conv stack: HBM-bound byte work, one element per thread,
 // coalesced on the side that moves the most bytes.
-//   pack_u8            : [N,H,W,3] u8 -> fp16 NHWC(32) plane with zero halo; replaces
+//   pack_u8            : [N,H,W,3] u8 -> one fp16 blocked-16 plane with zero halo; replaces
 //                        `img.astype(float32)/255` + permute (cnn_super_resolution.py:220-222);
 //                        values stay the exact integers 0..255, the 1/255 lives in conv_first.
 //   gather_windows     : cut the _tile_process windows (cnn_super_resolution.py:249-256)
@@ -12,7 +12,7 @@ namespace s2sr {
 typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 
-__global__ void pack_u8_kernel(const uint8_t* __restrict__ in, int N, int H, int W, char* __restrict__ plane, int Hp,
+__global__ void pack_u8_kernel(const uint8_t* __restrict__ in, int N, int H, int W, char* __restrict__ blk, int Hp,
                                int Wp) {
     const size_t total = (size_t)N * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -26,19 +26,20 @@ __global__ void pack_u8_kernel(const uint8_t* __restrict__ in, int N, int H, int
         v[1] = (f16)(float)s[1];
         v[2] = (f16)(float)s[2];
         v[3] = (f16)0.f;
-        *(f16x4*)(plane + (((size_t)n * Hp + y + 1) * Wp + x + 1) * 64) = v;
+        // one 16-channel block per image; channels 4..15 stay zero from the allocation memset
+        *(f16x4*)(blk + (((size_t)n * Hp + y + 1) * Wp + x + 1) * 32) = v;
     }
 }
 
-hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* plane, int Hp, int Wp, hipStream_t st) {
+hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_u8_kernel, dim3(grid), dim3(256), 0, st, d_tiles, N, H, W, plane, Hp, Wp);
+    hipLaunchKernelGGL(pack_u8_kernel, dim3(grid), dim3(256), 0, st, d_tiles, N, H, W, blk, Hp, Wp);
     return hipGetLastError();
 }
 
 __global__ void pack_f32_nchw_kernel(const float* __restrict__ x, int N, int C, int H, int W, float scale,
-                                     char* __restrict__ plane, int Cp, int Hp, int Wp) {
+                                     char* __restrict__ blk, int NB, int Hp, int Wp) {
     const size_t total = (size_t)N * C * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int xx = (int)(i % W);
@@ -47,16 +48,16 @@ __global__ void pack_f32_nchw_kernel(const float* __restrict__ x, int N, int C, 
         r /= H;
         const int c = (int)(r % C);
         const int n = (int)(r / C);
-        f16* d = (f16*)plane + (((size_t)n * Hp + y + 1) * Wp + xx + 1) * Cp + c;
+        f16* d = (f16*)(blk + ((((size_t)n * NB + (c >> 4)) * Hp + y + 1) * Wp + xx + 1) * 32) + (c & 15);
         *d = (f16)(x[i] * scale);
     }
 }
 
-hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* plane, int Cp, int Hp,
+hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB, int Hp,
                                 int Wp, hipStream_t st) {
     const size_t total = (size_t)N * C * H * W;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_f32_nchw_kernel, dim3(grid), dim3(256), 0, st, d_x, N, C, H, W, scale, plane, Cp, Hp, Wp);
+    hipLaunchKernelGGL(pack_f32_nchw_kernel, dim3(grid), dim3(256), 0, st, d_x, N, C, H, W, scale, blk, NB, Hp, Wp);
     return hipGetLastError();
 }
 

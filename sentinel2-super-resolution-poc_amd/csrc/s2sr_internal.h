@@ -9,65 +9,68 @@
 namespace s2sr {
 
 // ------------------------------------------------------------------------------------------
-// Activation planes.
+// Activation tensors in HBM: "blocked-16 with a physical zero halo".
 //
-// Every feature map lives in HBM as fp16 (or fp32) "NHWC with a physical zero halo":
-//   element (n, y, x, c)  ->  ((n*Hp + y+1)*Wp + x+1) * C + c
-// with Hp = roundup(H,32)+2, Wp = roundup(W,32)+2.  Kernels only ever store to pixels with
-// y<H, x<W, so the halo (and the round-up slack) stays zero from the allocation-time memset:
-// the 3x3 zero padding of the reference convs (cnn_super_resolution.py:78-82) and ragged
-// tile edges then need no bounds checks on the load side, which is what lets the loader be
-// a pure LDS-DMA stream.
+//   fp16 tensor, C channels (C % 16 == 0):   [N][C/16][Hp][Wp][16]   -> 32 B per (block, pixel)
+//   fp32 trunk tensors, 64 channels:         [N][8]   [Hp][Wp][8]    -> 32 B per (block, pixel)
+//   element (n, y, x) of block b sits at ((n*NB + b)*Hp + y+1)*Wp + x+1  (units of 32 B)
+//   with Hp = roundup(H,32)+2, Wp = roundup(W,32)+2.
+//
+// Why: the conv kernel consumes 16 input channels per pipeline stage.  With one plane per
+// 16-channel block a slab row (34 pixels) is 1088 CONTIGUOUS bytes, so every LDS-DMA
+// instruction (64 lanes x 16 B) reads 8 whole 128-B lines instead of 32 partial ones (the
+// NHWC layout of the first version cost ~20 % in the loader and produced multi-microsecond
+// stalls), and every epilogue store instruction writes 1 KiB contiguously.
+// Kernels only store to pixels with y<H, x<W, so halo and round-up slack stay zero from the
+// allocation-time memset: that IS the zero padding of the reference convs
+// (cnn_super_resolution.py:78-82) and it removes every bounds check from the loader.
+// The channel concatenation of the dense block (torch.cat, cnn_super_resolution.py:87-90) is
+// just "the first k blocks of the dense tensor": [x(4 blocks) | x1(2) | x2(2) | x3(2) | x4(2)].
 // ------------------------------------------------------------------------------------------
 static inline int roundup32(int v) { return (v + 31) & ~31; }
 static inline int padded(int v) { return roundup32(v) + 2; }
 
 enum Epilogue : int {
-    EPI_LRELU = 0,      // y = lrelu(acc)                  -> fp16 plane slice   (RDB conv1..4, up1, up2, hr)
-    EPI_RDB5 = 1,       // v = acc*0.2 + T ; T=v           -> fp16 X_next        (RDB conv5, rdb1/rdb2)
-    EPI_RDB5_RRDB = 2,  // v = (acc*0.2+T)*0.2 + R; T=R=v  -> fp16 X_next        (RDB conv5 of rdb3)
-    EPI_FIRST = 3,      // v = acc*in_scale + bias; F=T=R=v-> fp16 X             (conv_first)
+    EPI_LRELU = 0,      // y = lrelu(acc)                  -> fp16 blocks        (RDB conv1..4, up1, up2, hr)
+    EPI_RDB5 = 1,       // v = acc*0.2 + T ; T=v           -> fp16 x_next        (RDB conv5, rdb1/rdb2)
+    EPI_RDB5_RRDB = 2,  // v = (acc*0.2+T)*0.2 + R; T=R=v  -> fp16 x_next        (RDB conv5 of rdb3)
+    EPI_FIRST = 3,      // v = acc*in_scale + bias; F=T=R=v-> fp16 x             (conv_first)
     EPI_BODY = 4,       // v = F + acc                     -> fp16               (conv_body + trunk skip)
     EPI_LAST = 5,       // out fp32 NCHW and/or u8 NHWC (x255, clip, truncate)   (conv_last)
     EPI_DEBUG = 6,      // out fp32 NCHW, all Cout, optional lrelu               (s2sr_debug_conv)
 };
 
 struct ConvParams {
-    const char* src0;        // plane feeding chunks [0, split)
-    const char* src1;        // plane feeding chunks [split, nchunks)
-    uint32_t rec0, rec1;     // bytes per pixel record of src0 / src1
-    int32_t split, nchunks;  // 32-channel chunks
-    const void* wpack;       // packed fp16 weights in MFMA A-fragment order (see pack_conv_weights)
-    const float* bias;       // [CT*32] fp32, zero padded
+    const char* src;         // first input block of image 0 (fp16 blocked tensor)
+    uint64_t src_img;        // bytes between images of src
+    int32_t nstage;          // 16-channel input blocks consumed (= pipeline stages per patch)
+    const void* wpack;       // packed fp16 weights (pack_conv_weights)
+    const float* bias;       // [64] fp32, zero padded
     int32_t N, H, W;         // output logical dims (images in this launch)
-    int32_t Hp, Wp;          // padded dims of output-resolution planes
-    int32_t sHp, sWp;        // padded dims of the source planes (== Hp,Wp unless upsample-on-load)
-    int32_t tilesX, tilesY;
-    char* dst;               // fp16 destination plane
-    uint32_t dst_rec;        // bytes per pixel record of dst
-    uint32_t dst_coff;       // byte offset of this conv's first output channel inside the record
-    float* T; float* R; float* F;   // fp32 64-channel planes (trunk, RRDB skip, global skip)
-    float* out_f32;          // EPI_LAST / EPI_DEBUG: [N,Cout,H,W] fp32 (may be null)
+    int32_t Hp, Wp;          // padded dims at output resolution
+    int32_t sHp, sWp;        // padded dims of the source tensor (== Hp,Wp unless upsample-on-load)
+    int32_t tilesX, tilesY;  // filled by the launcher
+    char* dst;               // first OUTPUT block of image 0 (fp16 blocked tensor)
+    uint64_t dst_img;        // bytes between images of dst
+    float* T; float* R; float* F;   // fp32 blocked trunk tensors (8 blocks), image stride 8*Hp*Wp*32
+    float* out_f32;          // EPI_LAST / EPI_DEBUG: [N,cout,H,W] fp32 (may be null)
     uint8_t* out_u8;         // EPI_LAST: [N,H,W,3] u8 (may be null)
     int32_t cout;            // real output channels (EPI_LAST: 3; EPI_DEBUG: Cout)
     int32_t act;             // EPI_DEBUG: apply lrelu
     float in_scale;          // EPI_FIRST: 1/255 (inputs are fed as exact integers 0..255)
-    unsigned long long* trace;   // diagnostic builds only: s_memtime stamps, 24 per workgroup
+    unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
 };
 
-// conv kernel launchers (conv_mfma.hip).  ct = ceil(Cout/32) in {1,2}.
-hipError_t launch_conv_f16(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
-hipError_t launch_conv_f16_trace(const ConvParams& p, int ct, hipStream_t st);   // diagnostic build with stamps
-// version 2 (conv_ring.hip): persistent workgroups + LDS ring; its own weight layout
-hipError_t launch_conv_f16_ring(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
-void pack_conv_weights_ring(const float* w, int cin, int cout, float wscale, void* dst_host);
+// conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
+hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
 size_t conv_wpack_bytes(int cin, int cout);
-// host-side repack: OIHW fp32 -> fp16 A-fragment order, zero padded to 32-multiples
+// host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
 void pack_conv_weights(const float* w, int cin, int cout, float wscale, void* dst_host);
 
 // data-movement kernels (pack.hip)
-hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* plane, int Hp, int Wp, hipStream_t st);
-hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* plane, int Cp,
+hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);
+hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB,
                                 int Hp, int Wp, hipStream_t st);
 hipError_t launch_gather_windows(const uint8_t* d_img, int H, int W, const int32_t* d_rects, int T, int wh, int ww,
                                  uint8_t* d_tiles, hipStream_t st);

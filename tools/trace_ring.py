@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Stamp breakdown of the ring kernel's first stages (diagnostic build)."""
+import sys
+from pathlib import Path
+import numpy as np
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+from s2sr import native
+
+e = native.Engine(num_block=1)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for cin, cout in ((64, 32), (160, 32), (192, 64)):
+    us, tr = e.bench_conv(N, 256, 256, cin, cout, iters=20, trace_wgs=256)
+    fl = 2 * 9 * cin * cout * N * 65536
+    print(f"cin={cin} cout={cout} N={N}: {us:.1f} us/launch  {fl/us/1e6:.1f} TF/s")
+    tr = tr.astype(np.int64)
+    tr = tr[tr[:, 0] > 0]
+    nst = 7
+    med = lambda a, b: float(np.median(tr[:, b] - tr[:, a]))
+    print(f"   wgs {len(tr)}  setup+prologue {med(0,1):.0f}", end="")
+    for k in range(nst):
+        print(f" | s{k}: wait {med(1+3*k, 2+3*k):.0f} comp {med(2+3*k, 3+3*k):.0f}", end="")
+        if k < nst - 1:
+            print(f" gap {med(3+3*k, 4+3*k):.0f}", end="")
+    print()
