@@ -107,7 +107,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
 
 #define S2SR_STAMP(k)                                                              \
     do {                                                                           \
-        if (TRACE && p.trace && tid == 0 && (k) < 24)                              \
+        if (TRACE && p.trace && tid == 0 && (k) < 20)                              \
             p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
@@ -121,6 +121,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pcol = lane & 31, hh = lane >> 5;
     S2SR_STAMP(0);
+    if (TRACE && p.trace && tid == 0) {
+        p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
+    }
 
     // ---- my patches.  Round `it` of the grid covers tiles [it*nwg, (it+1)*nwg); inside a round
     // the workgroups that share an XCD (same blockIdx % 8) take one contiguous run of tiles, so
@@ -209,16 +213,22 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
             wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
             if (++st_i == NS) { st_i = 0; ++it_i; }
         }
+        // A fragment of tap t = dy*3+dx is first needed at B step t (slab row s = dy), so the 9 taps
+        // are fetched one step ahead of their first use instead of all up front: no LDS-read
+        // bubble behind the barrier.
         f16x8 a[9][CT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) a[t][ct] = *(const f16x8*)(buf + aaddr + (t * CT + ct) * 1024);
+        for (int ct = 0; ct < CT; ++ct) a[0][ct] = *(const f16x8*)(buf + aaddr + ct * 1024);
         f16x8 b[2];
         b[0] = *(const f16x8*)(buf + baddr[0][0]);
 #pragma unroll
         for (int step = 0; step < G::NBSTEP; ++step) {
             const int s = step / 3, dx = step % 3;
+            if (step + 1 < 9) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    a[step + 1][ct] = *(const f16x8*)(buf + aaddr + ((step + 1) * CT + ct) * 1024);
+            }
             if (step + 1 < G::NBSTEP) b[(step + 1) & 1] = *(const f16x8*)(buf + baddr[(step + 1) / 3][(step + 1) % 3]);
             if (do_issue) {
 #pragma unroll
@@ -424,6 +434,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                 ++k;
             }
         }
+    }
+    if (TRACE && p.trace && tid == 0) {
+        p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
     }
 }
 

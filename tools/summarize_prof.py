@@ -19,7 +19,7 @@ for f in glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True):
     for r in rows[:14]:
         print(f"  {short(r['Name']):70s} calls {r['Calls']:>6s} total_ns {r['TotalDurationNs']:>12s} avg_ns {r['AverageNs']:>12s} pct {r['Percentage']}")
 
-for p in sorted(glob.glob(f"{out}/pmc*/")):
+for p in sorted(glob.glob(f"{out}/pmc_*/")):
     files = glob.glob(f"{p}/**/*counter_collection.csv", recursive=True)
     if not files:
         continue

@@ -1,10 +1,8 @@
 #!/bin/bash
-# group-size / workgroup-shape sweep on one GPU
-mkdir -p gpurun_out
 for g in 2 4 8 16 32; do
-  python tools/quick_bench.py --batch 32 --steps 2 --group $g --prof 0 2>&1 | grep "B="
+  python tools/quick_bench.py --batch 32 --steps 2 --group $g --prof 1 2>&1 | grep -E "B=|rdb_conv"
 done
-echo "--- CT1 4 waves (2 WG/CU)"
-for g in 4 8 16; do
-  S2SR_CT1_WAVES=4 python tools/quick_bench.py --batch 32 --steps 2 --group $g --prof 1 2>&1 | grep -E "B=|rdb_conv"
+echo "--- 4 waves x 4 rows"
+for g in 4 8; do
+  S2SR_WAVES=4 python tools/quick_bench.py --batch 32 --steps 2 --group $g --prof 1 2>&1 | grep -E "B=|rdb_conv"
 done

@@ -15,11 +15,14 @@ for cin, cout in ((64, 32), (160, 32), (192, 64)):
     print(f"cin={cin} cout={cout} N={N}: {us:.1f} us/launch  {fl/us/1e6:.1f} TF/s")
     tr = tr.astype(np.int64)
     tr = tr[tr[:, 0] > 0]
-    nst = 7
+    nst = 9
     med = lambda a, b: float(np.median(tr[:, b] - tr[:, a]))
-    print(f"   wgs {len(tr)}  setup+prologue {med(0,1):.0f}", end="")
+    print(f"   wgs {len(tr)}  setup+prologue {med(0,1):.0f} first-wait {med(1,2):.0f}", end="")
     for k in range(nst):
-        print(f" | s{k}: wait {med(1+3*k, 2+3*k):.0f} comp {med(2+3*k, 3+3*k):.0f}", end="")
+        print(f" | s{k}: comp {med(2+2*k, 3+2*k):.0f}", end="")
         if k < nst - 1:
-            print(f" gap {med(3+3*k, 4+3*k):.0f}", end="")
+            print(f" wait {med(3+2*k, 4+2*k):.0f}", end="")
     print()
+    dt = (tr[:, 23] - tr[:, 22]).astype(float)
+    dr = (tr[:, 21] - tr[:, 20]).astype(float)
+    print(f"   whole-kernel per WG: {np.median(dt):.0f} shader ticks, {np.median(dr):.0f} realtime ticks (100 MHz) -> clock {np.median(dt/dr)*100:.0f} MHz")
