@@ -123,6 +123,16 @@ int  s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
 int  s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
                            int32_t tile, int32_t pad, float* out);
 
+/* Multi-GPU building blocks of _tile_process (cnn_super_resolution.py:244-278), device-resident:
+ * cut windows [first, first+count) of the plan into d_tiles [count, wh, ww, 3] (wh/ww = the
+ * plan's common window size), and paste ALL T windows' outputs d_tiles [T, 4wh, 4ww, 3] into
+ * d_out [4H, 4W, 3] with the reference's crop + overwrite order.  Between the two a rank runs
+ * s2sr_forward_batch_u8_dev on its share and the ranks all-gather (RCCL) the outputs. */
+int  s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                             int32_t first, int32_t count, void* d_tiles, void* stream);
+int  s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                                void* d_out, void* stream);
+
 /* replaces _enhance_for_crops (wow_sr.py:187-209) and enhance_local_contrast /
  * apply_unsharp_mask / enhance_vegetation (farm_sr.py:61-108): HxWx3 u8 RGB -> same. */
 int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W,

@@ -499,6 +499,22 @@ int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32
     return S2SR_OK;
 }
 
+// host-side maps of the paste rule; shared by enhance and the multi-GPU stitch
+static void build_stitch_maps(const std::vector<s2sr_window>& wins, int nx, int ny, int OH, int OW,
+                              std::vector<int32_t>& rm, std::vector<int32_t>& cm) {
+    rm.assign(2 * (size_t)OH, -1);
+    cm.assign(2 * (size_t)OW, -1);
+    // last window in loop order wins (:278): ascending index, later entries overwrite the map
+    for (int y = 0; y < ny; ++y) {
+        const s2sr_window& w = wins[(size_t)y * nx];
+        for (int oy = w.oy1; oy < w.oy2; ++oy) { rm[2 * oy] = y; rm[2 * oy + 1] = oy - w.oy1 + w.crop_top; }
+    }
+    for (int x = 0; x < nx; ++x) {
+        const s2sr_window& w = wins[x];
+        for (int ox = w.ox1; ox < w.ox2; ++ox) { cm[2 * ox] = x; cm[2 * ox + 1] = ox - w.ox1 + w.crop_left; }
+    }
+}
+
 // RealESRGAN.enhance (cnn_super_resolution.py:217-234) incl. _tile_process (:236-280)
 static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int tile, int pad, uint8_t* out_u8,
                         float* out_f32, bool force_tiled = false) {
@@ -540,19 +556,11 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         s2sr_plan_tiles(H, W, tile, pad, scale, wins.data(), T, &T);
         const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
         const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;   // all windows share one shape
-        std::vector<int32_t> rects(4 * T), rm(2 * OH, -1), cm(2 * OW, -1);
+        std::vector<int32_t> rects(4 * (size_t)T), rm, cm;
         for (int t = 0; t < T; ++t) {
             rects[4 * t] = wins[t].y1; rects[4 * t + 1] = wins[t].y2; rects[4 * t + 2] = wins[t].x1; rects[4 * t + 3] = wins[t].x2;
         }
-        // last window in loop order wins (:278): ascending index, later entries overwrite the map
-        for (int y = 0; y < ny; ++y) {
-            const s2sr_window& w = wins[y * nx];
-            for (int oy = w.oy1; oy < w.oy2; ++oy) { rm[2 * oy] = y; rm[2 * oy + 1] = oy - w.oy1 + w.crop_top; }
-        }
-        for (int x = 0; x < nx; ++x) {
-            const s2sr_window& w = wins[x];
-            for (int ox = w.ox1; ox < w.ox2; ++ox) { cm[2 * ox] = x; cm[2 * ox + 1] = ox - w.ox1 + w.crop_left; }
-        }
+        build_stitch_maps(wins, nx, ny, OH, OW, rm, cm);
         const size_t tin = (size_t)T * wh * ww * 3, tout = tin * 16;
         if ((rc = ensure_scratch(h, 2, tin))) return rc;
         if ((rc = ensure_scratch(h, 4, tout * (out_f32 ? 4 : 1)))) return rc;
@@ -583,6 +591,56 @@ int s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, in
 
 int s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
     return enhance_impl(h, img, H, W, tile, pad, nullptr, out);
+}
+
+int s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                            int32_t first, int32_t count, void* d_tiles, void* stream) {
+    if (!h || !d_img || !d_tiles || H <= 0 || W <= 0 || tile <= 0 || pad < 0 || first < 0 || count <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int T = 0;
+    s2sr_plan_tiles(H, W, tile, pad, 4, nullptr, 0, &T);
+    if (first + count > T) return fail(h, S2SR_E_INVALID, "window range exceeds the plan");
+    std::vector<s2sr_window> wins(T);
+    s2sr_plan_tiles(H, W, tile, pad, 4, wins.data(), T, &T);
+    const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;
+    std::vector<int32_t> rects(4 * (size_t)count);
+    for (int t = 0; t < count; ++t) {
+        const s2sr_window& w = wins[first + t];
+        rects[4 * t] = w.y1; rects[4 * t + 1] = w.y2; rects[4 * t + 2] = w.x1; rects[4 * t + 3] = w.x2;
+    }
+    int rc = ensure_scratch(h, 3, rects.size() * 4);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[3], rects.data(), rects.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, launch_gather_windows((const uint8_t*)d_img, H, W, (const int32_t*)h->d_scratch[3], count, wh, ww, (uint8_t*)d_tiles, st));
+    return S2SR_OK;
+}
+
+int s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                               void* d_out, void* stream) {
+    if (!h || !d_tiles || !d_out || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    int T = 0;
+    s2sr_plan_tiles(H, W, tile, pad, 4, nullptr, 0, &T);
+    std::vector<s2sr_window> wins(T);
+    s2sr_plan_tiles(H, W, tile, pad, 4, wins.data(), T, &T);
+    const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
+    const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;
+    std::vector<int32_t> rm, cm;
+    build_stitch_maps(wins, nx, ny, 4 * H, 4 * W, rm, cm);
+    int rc = ensure_scratch(h, 3, (rm.size() + cm.size()) * 4);
+    if (rc) return rc;
+    int32_t* d_rm = (int32_t*)h->d_scratch[3];
+    int32_t* d_cm = d_rm + rm.size();
+    HIPCHK(h, hipMemcpyAsync(d_rm, rm.data(), rm.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, launch_stitch_u8((const uint8_t*)d_tiles, nx, wh * 4, ww * 4, d_rm, d_cm, 4 * H, 4 * W, (uint8_t*)d_out, st));
+    return S2SR_OK;
 }
 
 int s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {

@@ -72,6 +72,8 @@ _PROTOS = {
     "s2sr_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_enhance_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tile_process_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_cut_windows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "s2sr_stitch_windows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
     "s2sr_postprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
     "s2sr_postprocess_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(PPParams), C.c_void_p, C.c_void_p]),
@@ -203,6 +205,16 @@ class Engine:
         self._check(self._lib.s2sr_tile_process_f32(self._h, _ptr(img), H, W, tile, pad, _ptr(out)),
                     "s2sr_tile_process_f32")
         return out
+
+    # -- multi-GPU building blocks (device pointers) ------------------------------------------
+    def cut_windows_u8_dev(self, d_img: int, H: int, W: int, tile: int, pad: int, first: int, count: int,
+                           d_tiles: int, stream: int = 0):
+        self._check(self._lib.s2sr_cut_windows_u8_dev(self._h, d_img, H, W, tile, pad, first, count, d_tiles,
+                                                      stream or None), "s2sr_cut_windows_u8_dev")
+
+    def stitch_windows_u8_dev(self, d_tiles: int, H: int, W: int, tile: int, pad: int, d_out: int, stream: int = 0):
+        self._check(self._lib.s2sr_stitch_windows_u8_dev(self._h, d_tiles, H, W, tile, pad, d_out, stream or None),
+                    "s2sr_stitch_windows_u8_dev")
 
     # -- post-process -----------------------------------------------------------------------
     def postprocess_u8(self, rgb: np.ndarray, prm: PPParams) -> np.ndarray:

@@ -1,0 +1,140 @@
+"""world_size-2 (and 3) gloo tests of the multi-GPU orchestration (s2sr/dist.py) on CPU.
+
+The compute backend is a numpy stand-in (nearest x4 + an affine map so that tile identity
+matters); what is under test is the sharding, tail padding, all-gather order, the paste rule
+and rank-count invariance: every world size must give byte-identical mosaics, equal to the
+single-process result and to the oracle's paste of the same fake model."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+PKG = REPO / "sentinel2-super-resolution-poc_amd"
+
+
+class FakeBackend:
+    """CPU stand-in with the NativeBackend interface; the model is nearest-x4 of (3*v+7) mod 256."""
+    device = torch.device("cpu")
+
+    def cut(self, img, tile, pad, first, count, slots, wh, ww):
+        from s2sr import native
+        H, W, _ = img.shape
+        wins = native.plan_tiles(H, W, tile, pad, 4)
+        out = torch.zeros((slots, wh, ww, 3), dtype=torch.uint8)
+        for i in range(count):
+            w = wins[first + i]
+            out[i] = img[w.y1:w.y2, w.x1:w.x2]
+        return out
+
+    def forward(self, tiles):
+        t = ((tiles.to(torch.int32) * 3 + 7) % 256).to(torch.uint8)
+        return t.repeat_interleave(4, 1).repeat_interleave(4, 2)
+
+    def stitch(self, tiles, H, W, tile, pad):
+        from s2sr import native
+        wins = native.plan_tiles(H, W, tile, pad, 4)
+        out = torch.zeros((4 * H, 4 * W, 3), dtype=torch.uint8)
+        for i, w in enumerate(wins):     # sequential paste == the reference's loop (:247-278)
+            t = tiles[i]
+            th, tw = t.shape[0], t.shape[1]
+            out[w.oy1:w.oy2, w.ox1:w.ox2] = t[w.crop_top:th - w.crop_bottom, w.crop_left:tw - w.crop_right]
+        return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cases, q):
+    for p in (str(PKG), str(REPO)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from s2sr import dist as sd
+    from s2sr.weights import synthetic_state_dict, flatten_state_dict
+    be = FakeBackend()
+    res = []
+    for (H, W, tile, pad, seed) in cases:
+        img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
+        res.append(sd.enhance_distributed(be, img, tile, pad))
+    tiles = np.random.default_rng(99).integers(0, 256, (5, 8, 12, 3), dtype=np.uint8)
+    res.append(sd.forward_batch_distributed(be, tiles))
+    blob = sd.broadcast_weights(synthetic_state_dict(1, seed=3) if rank == 0 else None, 1, torch.device("cpu"))
+    ok_blob = np.array_equal(blob, flatten_state_dict(synthetic_state_dict(1, seed=3), 1))
+    if rank == world - 1:      # the last rank (the one with the ragged tail) reports
+        q.put((res, ok_blob))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CASES = [(37, 45, 16, 2, 1), (33, 70, 16, 2, 2), (49, 48, 16, 2, 3), (20, 90, 16, 3, 4), (24, 24, 16, 2, 5)]
+
+
+def _run(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, CASES, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def _expected():
+    for p in (str(PKG), str(REPO)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import rrdbnet_ref as ref
+    exp = []
+    for (H, W, tile, pad, seed) in CASES:
+        img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
+        model = lambda a: np.repeat(np.repeat(((a.astype(np.int32) * 3 + 7) % 256).astype(np.uint8), 4, 0), 4, 1)
+        if H * W <= tile * tile * 4:
+            exp.append(model(img))
+            continue
+        out = np.zeros((4 * H, 4 * W, 3), np.uint8)
+        for (y1, y2, x1, x2), (top, bottom, left, right), (oy1, oy2, ox1, ox2) in ref.tile_plan(H, W, tile, pad, 4):
+            t = model(img[y1:y2, x1:x2])
+            out[oy1:oy2, ox1:ox2] = t[top:t.shape[0] - bottom, left:t.shape[1] - right]
+        exp.append(out)
+    return exp
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_count_invariance(world):
+    res, ok_blob = _run(world)
+    exp = _expected()
+    assert ok_blob
+    for got, e, case in zip(res[:-1], exp, CASES):
+        assert np.array_equal(got, e), case
+    tiles = np.random.default_rng(99).integers(0, 256, (5, 8, 12, 3), dtype=np.uint8)
+    e = np.repeat(np.repeat(((tiles.astype(np.int32) * 3 + 7) % 256).astype(np.uint8), 4, 1), 4, 2)
+    assert np.array_equal(res[-1], e)
+
+
+def test_shard_range_covers_everything():
+    from s2sr.dist import shard_range
+    for total in (0, 1, 5, 16, 17, 100):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                f, c, per = shard_range(total, world, r)
+                assert c <= per
+                seen += list(range(f, f + c))
+            assert seen == list(range(total))

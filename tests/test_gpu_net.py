@@ -150,3 +150,32 @@ def test_errors_are_loud():
     with pytest.raises(native.S2srError):
         e.load_blob(np.zeros(10, np.float32))                      # wrong blob size
     e.close()
+
+
+def test_cut_forward_stitch_equals_enhance():
+    """The multi-GPU building blocks (cut windows -> batch forward -> stitch) reproduce
+    s2sr_enhance_u8 byte for byte; also through s2sr.dist with a 1-rank process group."""
+    import os
+    import torch.distributed as dist
+    from s2sr.dist import NativeBackend, enhance_distributed
+    nb = 1
+    e = engine(nb)
+    rng = np.random.default_rng(31)
+    be = NativeBackend(e, 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        for (H, W, ts, tp) in [(37, 45, 16, 2), (64, 65, 32, 4), (20, 20, 16, 2)]:
+            img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+            exp = e.enhance_u8(img, tile=ts, pad=tp)
+            # gloo cannot all-gather CUDA tensors: with one rank the gather is the identity
+            dist_all = dist.all_gather_into_tensor
+            dist.all_gather_into_tensor = lambda out, inp: out.copy_(inp)
+            try:
+                got = enhance_distributed(be, img, ts, tp)
+            finally:
+                dist.all_gather_into_tensor = dist_all
+            assert np.array_equal(got, exp), (H, W)
+    finally:
+        dist.destroy_process_group()
