@@ -104,7 +104,8 @@ int  s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t sc
  * (cnn_super_resolution.py:140-158,220-222,231-232): [B,h,w,3] u8 -> [B,4h,4w,3] u8. */
 int  s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw,
                            uint8_t* out);
-/* same with device-resident input/output; `stream` is a hipStream_t or NULL (= handle stream) */
+/* same with device-resident input/output, asynchronous on `stream` (a hipStream_t; NULL = the
+ * default stream, ordered with the caller's other default-stream work) */
 int  s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, int32_t th, int32_t tw,
                                void* d_out, void* stream);
 /* unquantised net output for parity tests: x [N,3,H,W] fp32 in [0,1] -> y [N,3,4H,4W] fp32 */

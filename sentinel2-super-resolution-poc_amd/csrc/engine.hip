@@ -283,7 +283,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
 }
 
 int group_size(const s2sr_handle* h, int B, int H, int W) {
-    int g = h->cfg.group > 0 ? h->cfg.group : 8;
+    int g = h->cfg.group > 0 ? h->cfg.group : 16;
     // keep the workspace modest (<= ~24 GiB)
     const double per_img = (double)padded(H) * padded(W) * 1696.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
                            (double)padded(4 * H) * padded(4 * W) * 256.0;
@@ -461,7 +461,7 @@ int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, in
     if (!h || !d_tiles || !d_out) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
     return forward_dev(h, st, (const uint8_t*)d_tiles, nullptr, B, th, tw, (uint8_t*)d_out, nullptr);
 }
 
@@ -598,7 +598,7 @@ int s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32_
     if (!h || !d_img || !d_tiles || H <= 0 || W <= 0 || tile <= 0 || pad < 0 || first < 0 || count <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
     int T = 0;
     s2sr_plan_tiles(H, W, tile, pad, 4, nullptr, 0, &T);
     if (first + count > T) return fail(h, S2SR_E_INVALID, "window range exceeds the plan");
@@ -623,7 +623,7 @@ int s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, i
     if (!h || !d_tiles || !d_out || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
     int T = 0;
     s2sr_plan_tiles(H, W, tile, pad, 4, nullptr, 0, &T);
     std::vector<s2sr_window> wins(T);
@@ -652,7 +652,7 @@ int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, 
     if (!h || !d_rgb || !d_out || !prm || B <= 0 || H <= 0 || W <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
     const size_t wb = postprocess_work_bytes(B, H, W, *prm);
     int rc = ensure_scratch(h, 5, wb);
     if (rc) return rc;
@@ -672,7 +672,7 @@ int s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W
         if ((rc = ensure_scratch(h, 1, nb))) return rc;
         HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgb, nb, hipMemcpyHostToDevice, h->stream));
     }
-    int rc = s2sr_postprocess_batch_u8_dev(h, h->d_scratch[0], 1, H, W, prm, h->d_scratch[1], nullptr);
+    int rc = s2sr_postprocess_batch_u8_dev(h, h->d_scratch[0], 1, H, W, prm, h->d_scratch[1], (void*)h->stream);
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], nb, hipMemcpyDeviceToHost, h->stream));

@@ -172,7 +172,7 @@ class Engine:
 
     def forward_batch_u8_dev(self, d_in: int, B: int, h: int, w: int, d_out: int, stream: int = 0):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); asynchronous on `stream`."""
-        self._check(self._lib.s2sr_forward_batch_u8_dev(self._h, d_in, B, h, w, d_out, stream or None),
+        self._check(self._lib.s2sr_forward_batch_u8_dev(self._h, d_in, B, h, w, d_out, C.c_void_p(stream)),
                     "s2sr_forward_batch_u8_dev")
 
     def forward_f32(self, x: np.ndarray) -> np.ndarray:
@@ -210,10 +210,10 @@ class Engine:
     def cut_windows_u8_dev(self, d_img: int, H: int, W: int, tile: int, pad: int, first: int, count: int,
                            d_tiles: int, stream: int = 0):
         self._check(self._lib.s2sr_cut_windows_u8_dev(self._h, d_img, H, W, tile, pad, first, count, d_tiles,
-                                                      stream or None), "s2sr_cut_windows_u8_dev")
+                                                      C.c_void_p(stream)), "s2sr_cut_windows_u8_dev")
 
     def stitch_windows_u8_dev(self, d_tiles: int, H: int, W: int, tile: int, pad: int, d_out: int, stream: int = 0):
-        self._check(self._lib.s2sr_stitch_windows_u8_dev(self._h, d_tiles, H, W, tile, pad, d_out, stream or None),
+        self._check(self._lib.s2sr_stitch_windows_u8_dev(self._h, d_tiles, H, W, tile, pad, d_out, C.c_void_p(stream)),
                     "s2sr_stitch_windows_u8_dev")
 
     # -- post-process -----------------------------------------------------------------------
@@ -228,7 +228,7 @@ class Engine:
 
     def postprocess_batch_u8_dev(self, d_in: int, B: int, H: int, W: int, prm: PPParams, d_out: int, stream: int = 0):
         self._check(self._lib.s2sr_postprocess_batch_u8_dev(self._h, d_in, B, H, W, C.byref(prm), d_out,
-                                                            stream or None), "s2sr_postprocess_batch_u8_dev")
+                                                            C.c_void_p(stream)), "s2sr_postprocess_batch_u8_dev")
 
     # -- measurement ------------------------------------------------------------------------
     def set_profiling(self, every: int):
