@@ -1,0 +1,73 @@
+"""Host-side mirror of the reference seam (app.*): names, errors, state-dict compatibility and
+the PIL raster I/O -- everything that does not need a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from s2sr import rasterio_lite as rio
+from s2sr.weights import synthetic_state_dict
+
+
+def test_models_table_and_errors(tmp_path, monkeypatch):
+    import app.cnn_super_resolution as m
+    assert set(m.MODELS) == {"realesrgan_x4", "realesrgan_anime"}
+    assert m.MODELS["realesrgan_x4"]["blocks"] == 23 and m.MODELS["realesrgan_anime"]["blocks"] == 6
+    assert all(v["scale"] == 4 and v["channels"] == 64 and v["num_in_ch"] == 3 for v in m.MODELS.values())
+    with pytest.raises(ValueError, match="Unknown model"):
+        m.download_weights("realesrgan_x2")
+    monkeypatch.setenv("S2SR_MODEL_DIR", str(tmp_path))
+    monkeypatch.delenv("S2SR_ALLOW_DOWNLOAD", raising=False)
+    with pytest.raises(FileNotFoundError):
+        m.download_weights("realesrgan_x4")          # never reaches the network
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.RealESRGAN(device="cpu")
+    # scale 2|3 -> "realesrgan_x2|3" is not in MODELS -> ValueError like the reference (farm_sr.py:162)
+    if torch.cuda.is_available():
+        with pytest.raises(ValueError, match="Unknown model"):
+            m.RealESRGAN(scale=2)
+
+
+def test_rrdbnet_shell_is_state_dict_compatible():
+    import app.cnn_super_resolution as m
+    for nb in (6, 23):
+        net = m.RRDBNet(num_block=nb)
+        sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(nb, seed=0).items()}
+        assert list(net.state_dict().keys()) == list(sd.keys())
+        net.load_state_dict(sd, strict=True)
+        assert sum(p.numel() for p in net.parameters()) == (16_697_987 if nb == 23 else sum(v.numel() for v in sd.values()))
+    bad = dict(sd)
+    bad.pop("conv_last.bias")
+    with pytest.raises(RuntimeError):
+        m.RRDBNet(num_block=23).load_state_dict(bad, strict=True)
+
+
+def test_select_params_like_the_reference():
+    from s2sr.weights import select_params
+    assert select_params({"params_ema": 1, "params": 2}) == 1
+    assert select_params({"params": 2}) == 2
+    assert select_params({"conv_first.weight": 3}) == {"conv_first.weight": 3}
+
+
+def test_raster_io_roundtrip(tmp_path):
+    rgb = np.random.default_rng(0).integers(0, 256, (33, 47, 3), dtype=np.uint8)
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0),
+                      rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 500000.0, 4000000.0, 0.0),
+                      rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32636)})
+    p = tmp_path / "a.tif"
+    rio.write_geotiff_rgb(p, rgb, geo)
+    img, g2 = rio.read_rgb_u8(p)
+    assert np.array_equal(img, rgb) and g2.pixel_size == (10.0, 10.0)
+    g4 = g2.scaled(4)
+    assert g4.pixel_size == (2.5, 2.5) and g4.tags[rio.TAG_TIEPOINT] == geo.tags[rio.TAG_TIEPOINT]
+    # png: no georeference (the reference's suffix switch, wow_sr.py:59,77)
+    q = tmp_path / "a.png"
+    rio.write_png(q, rgb)
+    img2, none = rio.read_rgb_u8(q)
+    assert none is None and np.array_equal(img2, rgb)
+    # 16-bit single band, max > 255 -> min-max to u8 with truncation (wow_sr.py:67-71)
+    from PIL import Image
+    band = np.random.default_rng(1).integers(100, 4000, (20, 30)).astype(np.uint16)
+    Image.fromarray(band).save(tmp_path / "b.tif")
+    img3, _ = rio.read_rgb_u8(tmp_path / "b.tif")
+    exp = ((band - band.min()) / (band.max() - band.min()) * 255).astype(np.uint8)
+    assert np.array_equal(img3[..., 0], exp) and np.array_equal(img3[..., 0], img3[..., 2])

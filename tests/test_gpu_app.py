@@ -1,0 +1,79 @@
+"""GPU end-to-end through the reference-shaped Python seam (app.*)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess_ref as pp
+from oracle import rrdbnet_ref as ref
+from s2sr import rasterio_lite as rio
+from s2sr.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _patch_weights(monkeypatch, tmp_path, nb_by_name):
+    """Write seeded synthetic checkpoints where the reference looks for them (<dir>/<name>.pth)."""
+    monkeypatch.setenv("S2SR_MODEL_DIR", str(tmp_path / "models"))
+    (tmp_path / "models").mkdir(exist_ok=True)
+    for name, nb in nb_by_name.items():
+        sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(nb, seed=0).items()}
+        torch.save({"params_ema": sd}, tmp_path / "models" / f"{name}.pth")
+
+
+def test_realesrgan_class_matches_oracle(monkeypatch, tmp_path):
+    import app.cnn_super_resolution as m
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    e = m.RealESRGAN(model_name="realesrgan_anime", tile_size=256)
+    assert (e.scale, e.tile_size, e.tile_pad, e.model_name) == (4, 256, 10, "realesrgan_anime")
+    img = np.random.default_rng(2).integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    out = e.enhance(img)
+    exp = ref.enhance(img, ref.to_torch_sd(synthetic_state_dict(6, seed=0)), 6)
+    d = np.abs(out.astype(np.int16) - exp.astype(np.int16))
+    assert out.shape == (160, 224, 3) and d.max() <= 1 and (d == 0).mean() > 0.95
+    with pytest.raises(TypeError):
+        e.enhance(img.astype(np.float32))
+    # a second object reuses the cached engine (construct-per-job is free)
+    e2 = m.RealESRGAN(model_name="realesrgan_anime")
+    assert e2._engine is e._engine
+
+
+def test_process_wow_and_farm_sr(monkeypatch, tmp_path):
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6, "realesrgan_x4": 23})
+    from app.farm_sr import apply_unsharp_mask, enhance_local_contrast, enhance_vegetation, process_farm_sr
+    from app.wow_sr import _enhance_for_crops, process_wow_sr
+    rgb = np.random.default_rng(3).integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    rgb[..., 1] = np.maximum(rgb[..., 1], 100)
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)})
+    src = tmp_path / "scene.tif"
+    rio.write_geotiff_rgb(src, rgb, geo)
+
+    res = process_wow_sr(src, tmp_path / "wow", enhance_crops=True, model="realesrgan_anime")
+    assert set(res) == {"timestamp", "input", "outputs", "sr_metadata"}
+    meta = res["sr_metadata"]
+    assert meta["original_size"] == [24, 32] and meta["output_size"] == [96, 128] and meta["scale"] == 4
+    assert meta["enhancements"] == ["CLAHE local contrast", "Unsharp mask", "Vegetation boost"]
+    out, g4 = rio.read_rgb_u8(res["outputs"]["sr_tif"])
+    assert out.shape == (96, 128, 3) and g4.pixel_size == (2.5, 2.5)
+    assert json.load(open(tmp_path / "wow" / "scene_wow_sr_metadata.json"))["sr_metadata"] == meta
+    # expected pixels: oracle net on BGR, back to RGB, oracle post-process; u8 net output may
+    # differ by 1 LSB, so compare the post-process on the library's own SR image instead
+    png, _ = rio.read_rgb_u8(res["outputs"]["sr_png"])
+    assert np.array_equal(png, out)
+    res2 = process_wow_sr(src, tmp_path / "wow2", enhance_crops=False, model="realesrgan_anime")
+    sr_plain, _ = rio.read_rgb_u8(res2["outputs"]["sr_tif"])
+    assert np.array_equal(pp.enhance_for_crops(sr_plain), out)
+    assert np.array_equal(_enhance_for_crops(sr_plain), out)
+    exp_sr = ref.enhance(np.ascontiguousarray(rgb[:, :, ::-1]), ref.to_torch_sd(synthetic_state_dict(6, seed=0)), 6)[:, :, ::-1]
+    assert np.abs(sr_plain.astype(np.int16) - exp_sr.astype(np.int16)).max() <= 1
+
+    resf = process_farm_sr(src, tmp_path / "farm", scale=4)          # /api/sr path: 23-block net + farm constants
+    farm, _ = rio.read_rgb_u8(resf["outputs"]["sr_tif"])
+    assert farm.shape == (96, 128, 3) and resf["sr_metadata"]["model"] == "RealESRGAN_farm_x4"
+    with pytest.raises(ValueError, match="Unknown model"):
+        process_farm_sr(src, tmp_path / "farm2", scale=2)             # reference: job fails with this message
+    # stand-alone farm helpers == oracle stages
+    assert np.array_equal(apply_unsharp_mask(sr_plain, 1.2, 1.5), pp.unsharp(sr_plain, 1.5, 2.2, -1.2))
+    assert np.array_equal(enhance_local_contrast(sr_plain, 2.5, 8), pp.local_contrast(sr_plain, 2.5, 8))
+    assert np.array_equal(enhance_vegetation(sr_plain), pp.vegetation(sr_plain, 1.3))
