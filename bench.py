@@ -128,9 +128,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
 
-    # ---- timed region: exactly K steps.  Every 8th launch of each kernel family is bracketed
+    # ---- timed region: exactly K steps.  Every 7th launch of each kernel family is bracketed
     # by a hipEvent pair on the launch stream (sampling keeps the event overhead < 1 %).
-    eng.set_profiling(8)
+    eng.set_profiling(7)
     eng.reset_kernel_stats()
     torch.cuda.synchronize()
     barrier()
@@ -162,7 +162,9 @@ def main():
         pmc = REPO / "profiles" / "pmc_summary.json"
         if pmc.exists():
             try:
-                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+                per_img = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_image")
+                imgs = min(a.group if a.group > 0 else 16, B)      # images per launch (engine group)
+                traffic = per_img * imgs if per_img else None
             except Exception:
                 traffic = None
         line = {
