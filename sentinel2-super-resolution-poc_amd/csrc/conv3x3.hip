@@ -70,21 +70,22 @@ __device__ __forceinline__ const char* uniform_ptr(const char* q) {
 }
 
 // LDS-DMA, 16 B per lane: LDS[lds_addr + lane*16] <- global[base + voff].  M0 is written in the
-// statement that uses it and restored; s_nop 4 covers SGPR operands that come straight from
-// v_readfirstlane.
-__device__ __forceinline__ void glds16(const char* base_, uint32_t voff, uint32_t lds_addr_) {
-    const char* base = uniform_ptr(base_);
-    const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_addr_);
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(base), "s"(lds_addr)
-        : "memory");
+// statement that uses it (hipcc keeps nothing live in M0 across statements in this kernel: no
+// other LDS-DMA, GWS, sendmsg or movrel user), one wait state between the M0 write and the DMA.
+// FORCE_UNIFORM re-derives base / lds_addr through v_readfirstlane: only the stamped diagnostic
+// build needs it (its divergent stamp branches make hipcc keep these uniform values in VGPRs,
+// which an "s" operand cannot take); s_nop 4 then covers the VALU-written SGPRs.
+template <bool FORCE_UNIFORM>
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, uint32_t lds_addr) {
+    if (FORCE_UNIFORM) {
+        base = uniform_ptr(base);
+        lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr)
+                     : "memory");
+    }
 }
 
 // 16-B global load hidden from hipcc's waitcnt bookkeeping; valid only after an explicit
@@ -95,7 +96,8 @@ __device__ __forceinline__ f32x4 asm_load16(const float* addr) {
     return r;
 }
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : __fmul_rn(v, 0.2f); }
+// LeakyReLU(0.2): max(v, 0.2v) is the same value for every finite v and one VALU op shorter
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0.2f)); }
 
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                     int j = wave + sl * WAVES;
                     if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
                     const uint32_t dst = lds0 + sl_off + (uint32_t)j * 1024;
-                    glds16(j < G::PI ? sb : wb, loff[sl], dst);
+                    glds16<(TRACE || EPI == EPI_DEBUG)>(j < G::PI ? sb : wb, loff[sl], dst);
                 }
             }
 #pragma unroll
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                 for (int sl = 0; sl < G::PW; ++sl) {
                     int j = wave + sl * WAVES;
                     if (j > G::NSTI - 1) j = G::NSTI - 1;
-                    glds16(j < G::PI ? sb : wb, loff[sl], lds0 + (uint32_t)(r * G::STAGE_BYTES) + (uint32_t)j * 1024);
+                    glds16<(TRACE || EPI == EPI_DEBUG)>(j < G::PI ? sb : wb, loff[sl], lds0 + (uint32_t)(r * G::STAGE_BYTES) + (uint32_t)j * 1024);
                 }
             }
         }
