@@ -97,6 +97,18 @@ __device__ __forceinline__ f32x4 asm_load16(const float* addr) {
 }
 
 // LeakyReLU(0.2): max(v, 0.2v) is the same value for every finite v and one VALU op shorter
+__device__ __forceinline__ u32x2 asm_load8(const char* addr) {
+    u32x2 r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ f32x4 half4_to_float(u32x2 h) {
+    const f16x4 v = __builtin_bit_cast(f16x4, h);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+    return o;
+}
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0.2f)); }
 
 template <int N>
@@ -180,6 +192,18 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
         }
     const uint32_t aaddr = G::PLANE + lane * 16;
 
+    // conv5 forms: the trunk is carried as an fp16 pair (hi = the x the convs read, lo = what fp16
+    // lost), t = hi + lo.  hi of this patch's own pixels is picked out of the slab planes while
+    // the first four stages (the 64 channels of x) are in LDS -- it never comes from HBM again.
+    constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
+    u32x2 hi_cap[4][NP][2];
+    uint32_t caddr[NP];
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+        const int q = (wave * NP + np + 1) * G::SW + pcol + 1;
+        caddr[np] = (uint32_t)(q * 32 + 16 * ((q >> 3) & 1) + 8 * hh);   // half 0; half 1 is at ^16
+    }
+
     f32x16 acc[CT][NP];
     auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -198,7 +222,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
 
     // One stage.  `do_issue` (workgroup-uniform): also issue the DMA of the stage R-1 ahead into
     // LDS slot `sl_off`, one instruction per B step, between the MFMAs.
-    auto stage_body = [&](const char* buf, bool do_issue, uint32_t sl_off) __attribute__((always_inline)) {
+    auto stage_body = [&](const char* buf, bool do_issue, uint32_t sl_off, int r, bool capture) __attribute__((always_inline)) {
+        if (kTrunk && r < 4 && capture) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np) {
+                hi_cap[r < 4 ? r : 0][np][0] = *(const u32x2*)(buf + caddr[np]);
+                hi_cap[r < 4 ? r : 0][np][1] = *(const u32x2*)(buf + (caddr[np] ^ 16));
+            }
+        }
         const char* sb = nullptr;
         const char* wb = nullptr;
         if (do_issue) {
@@ -269,19 +300,22 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
             ok[np] = (y < p.H) && (x < p.W);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
-        const size_t tn = (size_t)n * 8 * oblk;   // image offset inside a trunk tensor (bytes)
+        const size_t tn = (size_t)n * 8 * oblk;   // image offset inside an fp32 skip tensor (R, F), bytes
+        const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensor, bytes
         // residual operands: one burst of independent loads (padded tensors make every address
-        // valid, so they are unconditional).  The RRDB form has twice as many; it loads them per
-        // output row to stay inside the register budget of an 8-wave workgroup.
-        f32x4 res0[CT][NP][4], res1[CT][NP][4];
+        // valid, so they are unconditional); asm loads + one explicit wait, see asm_load16.
+        u32x2 lo_old[CT][NP][4];
+        f32x4 res1[CT][NP][4];
+        f32x4 res0[CT][NP][4];   // EPI_BODY only
         auto load_res = [&](int np) __attribute__((always_inline)) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const size_t o = tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16;
-                    res0[ct][np][g] = asm_load16((const float*)((const char*)p.T + o));
-                    if (EPI == EPI_RDB5_RRDB) res1[ct][np][g] = asm_load16((const float*)((const char*)p.R + o));
+                    lo_old[ct][np][g] = asm_load8((const char*)p.T + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 +
+                                                  (g & 1) * 16 + hh * 8);
+                    if (EPI == EPI_RDB5_RRDB)
+                        res1[ct][np][g] = asm_load16((const float*)((const char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16));
                 }
         };
         if (EPI == EPI_RDB5) {
@@ -308,7 +342,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                u32x2 hpk[4];   // fp16 x4 per g
+                u32x2 hpk[4];   // fp16 x4 per g (hi / plain output)
+                u32x2 lpk[4];   // fp16 x4 per g (lo), trunk forms and conv_first
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cb = ct * 32 + 8 * g + 4 * hh;   // first of this lane's 4 consecutive couts
@@ -319,24 +354,21 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                     if (EPI == EPI_LRELU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
-                    } else if (EPI == EPI_RDB5) {
+                    } else if (kTrunk) {
+                        // t = hi + lo (exact in fp32); hi was captured from LDS: block ct*2 + (g>>1), half g&1
+                        const f32x4 th = half4_to_float(hi_cap[(ct * 2 + (g >> 1)) & 3][np][g & 1]);
+                        const f32x4 tl = half4_to_float(lo_old[ct][np][g]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res0[ct][np][g][i]);
-                        if (ok[np]) *(f32x4*)((char*)p.T + to) = v;
-                    } else if (EPI == EPI_RDB5_RRDB) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            v[i] = __fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(v[i], 0.2f), res0[ct][np][g][i]), 0.2f),
-                                             res1[ct][np][g][i]);
-                        if (ok[np]) {
-                            *(f32x4*)((char*)p.T + to) = v;
-                            *(f32x4*)((char*)p.R + to) = v;
+                        for (int i = 0; i < 4; ++i) {
+                            const float t = __fadd_rn(th[i], tl[i]);
+                            v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), t);
+                            if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res1[ct][np][g][i]);
                         }
+                        if (EPI == EPI_RDB5_RRDB && ok[np]) *(f32x4*)((char*)p.R + to) = v;
                     } else if (EPI == EPI_FIRST) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], p.in_scale), p.bias[cb + i]);
                         if (ok[np]) {
-                            *(f32x4*)((char*)p.T + to) = v;
                             *(f32x4*)((char*)p.R + to) = v;
                             *(f32x4*)((char*)p.F + to) = v;
                         }
@@ -363,6 +395,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
                         hpk[g] = __builtin_bit_cast(u32x2, hv);
+                        if (kTrunk || EPI == EPI_FIRST) {
+                            f16x4 lv;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lv[i] = (f16)__fsub_rn(v[i], (float)hv[i]);
+                            lpk[g] = __builtin_bit_cast(u32x2, lv);
+                        }
                     }
                 }
                 if (EPI != EPI_LAST && EPI != EPI_DEBUG) {
@@ -378,6 +416,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                         if (ok[np])
                             *(u32x4*)(p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16) = o;
+                        if (kTrunk || EPI == EPI_FIRST) {
+                            u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
+                            const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
+                            const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
+                            u32x4 ol;
+                            ol[0] = q0[0]; ol[1] = q1[0]; ol[2] = q0[1]; ol[3] = q1[1];
+                            if (ok[np]) *(u32x4*)((char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16) = ol;
+                        }
                     }
                 }
             }
@@ -425,7 +471,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                 if (k + (R - 2) < S) wait_vm_barrier<G::PW*(R - 2)>();
                 else wait_vm_barrier<0>();
                 S2SR_STAMP(2 + 2 * k);
-                stage_body(smem + r * G::STAGE_BYTES, k + (R - 1) < S, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES));
+                stage_body(smem + r * G::STAGE_BYTES, k + (R - 1) < S, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), r,
+                           st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
                 S2SR_STAMP(3 + 2 * k);
                 if (++st_c == NS) {
                     epilogue(it_c);
@@ -467,6 +514,8 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         attr_set = true;
     }
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage % R != 0 || p.nstage < 4))
+        return hipErrorInvalidValue;   // the trunk forms pick x out of ring slots 0..3 (see hi_cap)
     ConvParams q = p;
     q.tilesX = (p.W + G::TW - 1) / G::TW;
     q.tilesY = (p.H + G::TH - 1) / G::TH;

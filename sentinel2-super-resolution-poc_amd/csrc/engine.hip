@@ -38,7 +38,8 @@ struct Workspace {
     char *P0 = nullptr;                  // input, 1 block
     char *D[2] = {nullptr, nullptr};     // dense-block tensors, 12 blocks: [x(4) | x1 | x2 | x3 | x4]
     char *U0 = nullptr;                  // 4 blocks
-    float *T = nullptr, *R = nullptr, *F = nullptr;   // fp32 trunk / RRDB skip / global skip
+    char *T = nullptr;                   // trunk lo (fp16, 4 blocks)
+    float *R = nullptr, *F = nullptr;    // fp32 RRDB skip / global skip (8 blocks of 8)
     // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
@@ -140,7 +141,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
     const size_t g = (size_t)G;
     const size_t oP0 = take(g * w.blk1), oD0 = take(g * 12 * w.blk1), oD1 = take(g * 12 * w.blk1),
-                 oU0 = take(g * 4 * w.blk1), oT = take(g * 8 * w.blk1), oR = take(g * 8 * w.blk1),
+                 oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oR = take(g * 8 * w.blk1),
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
     w.bytes = off;
@@ -148,7 +149,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
     HIPCHK(h, hipDeviceSynchronize());
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.U0 = w.base + oU0;
-    w.T = (float*)(w.base + oT); w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
+    w.T = w.base + oT; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
     return S2SR_OK;
 }
@@ -209,9 +210,9 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
     if (epi == EPI_LAST) bytes += px * 3.0 * ((p.out_u8 ? 1.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0));
     else bytes += px * cw.cout * 2.0;
-    if (epi == EPI_RDB5) bytes += px * 64 * 8.0;
-    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * 16.0;
-    if (epi == EPI_FIRST) bytes += px * 64 * 12.0;
+    if (epi == EPI_RDB5) bytes += px * 64 * 4.0;          // lo: fp16 read + write
+    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * 12.0;    // lo r/w + R fp32 r/w
+    if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
     HIPCHK(h, launch_conv(p, cw.ct, epi, up, st));
@@ -285,7 +286,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
 int group_size(const s2sr_handle* h, int B, int H, int W) {
     int g = h->cfg.group > 0 ? h->cfg.group : 16;
     // keep the workspace modest (<= ~24 GiB)
-    const double per_img = (double)padded(H) * padded(W) * 1696.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
+    const double per_img = (double)padded(H) * padded(W) * 1568.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
                            (double)padded(4 * H) * padded(4 * W) * 256.0;
     while (g > 1 && per_img * g > 24.0 * 1024 * 1024 * 1024) --g;
     if (g > B) g = B;
@@ -767,12 +768,14 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     const int Hp = padded(H), Wp = padded(W);
     const size_t blk = (size_t)Hp * Wp * 32;
     char *D0 = nullptr, *D1 = nullptr, *d_w = nullptr;
-    float *T = nullptr, *d_b = nullptr;
+    char* T = nullptr;
+    float *Rr = nullptr, *d_b = nullptr;
     unsigned long long* d_tr = nullptr;
     const size_t wb = conv_wpack_bytes(cin, cout), db = (size_t)N * 12 * blk;
     HIPCHK(h, hipMalloc((void**)&D0, db));
     HIPCHK(h, hipMalloc((void**)&D1, db));
-    HIPCHK(h, hipMalloc((void**)&T, (size_t)N * 8 * blk));
+    HIPCHK(h, hipMalloc((void**)&T, (size_t)N * 4 * blk));
+    HIPCHK(h, hipMalloc((void**)&Rr, (size_t)N * 8 * blk));
     HIPCHK(h, hipMalloc((void**)&d_w, wb));
     HIPCHK(h, hipMalloc((void**)&d_b, 256));
     // pseudo-random fp16 bit patterns (finite, |v| < 2)
@@ -786,12 +789,13 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     HIPCHK(h, hipMemcpy(D0, pat.data(), db, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_w, pat.data(), wb, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(D1, 0, db));
-    HIPCHK(h, hipMemset(T, 0, (size_t)N * 8 * blk));
+    HIPCHK(h, hipMemset(T, 0, (size_t)N * 4 * blk));
+    HIPCHK(h, hipMemset(Rr, 0, (size_t)N * 8 * blk));
     HIPCHK(h, hipMemset(d_b, 0, 256));
     ConvParams p{};
     p.src = D0; p.src_img = 12 * blk; p.nstage = cin / 16;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
-    p.T = T; p.R = T; p.F = T;
+    p.T = T; p.R = Rr; p.F = Rr;
     int epi;
     if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }
     else { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_RDB5; }
@@ -819,7 +823,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
         hipFree(d_tr);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(D0); hipFree(D1); hipFree(T); hipFree(d_w); hipFree(d_b);
+    hipFree(D0); hipFree(D1); hipFree(T); hipFree(Rr); hipFree(d_w); hipFree(d_b);
     return S2SR_OK;
 }
 

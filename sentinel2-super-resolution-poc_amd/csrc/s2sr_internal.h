@@ -32,9 +32,9 @@ static inline int padded(int v) { return roundup32(v) + 2; }
 
 enum Epilogue : int {
     EPI_LRELU = 0,      // y = lrelu(acc)                  -> fp16 blocks        (RDB conv1..4, up1, up2, hr)
-    EPI_RDB5 = 1,       // v = acc*0.2 + T ; T=v           -> fp16 x_next        (RDB conv5, rdb1/rdb2)
-    EPI_RDB5_RRDB = 2,  // v = (acc*0.2+T)*0.2 + R; T=R=v  -> fp16 x_next        (RDB conv5 of rdb3)
-    EPI_FIRST = 3,      // v = acc*in_scale + bias; F=T=R=v-> fp16 x             (conv_first)
+    EPI_RDB5 = 1,       // v = acc*0.2 + (x+lo)            -> fp16 x_next, lo    (RDB conv5, rdb1/rdb2)
+    EPI_RDB5_RRDB = 2,  // v = (acc*0.2+(x+lo))*0.2 + R; R=v-> fp16 x_next, lo    (RDB conv5 of rdb3)
+    EPI_FIRST = 3,      // v = acc*in_scale + bias; F=R=v  -> fp16 x, lo          (conv_first)
     EPI_BODY = 4,       // v = F + acc                     -> fp16               (conv_body + trunk skip)
     EPI_LAST = 5,       // out fp32 NCHW and/or u8 NHWC (x255, clip, truncate)   (conv_last)
     EPI_DEBUG = 6,      // out fp32 NCHW, all Cout, optional lrelu               (s2sr_debug_conv)
@@ -52,7 +52,8 @@ struct ConvParams {
     int32_t tilesX, tilesY;  // filled by the launcher
     char* dst;               // first OUTPUT block of image 0 (fp16 blocked tensor)
     uint64_t dst_img;        // bytes between images of dst
-    float* T; float* R; float* F;   // fp32 blocked trunk tensors (8 blocks), image stride 8*Hp*Wp*32
+    char* T;                 // trunk 'lo' tensor: fp16 blocked-16, 4 blocks (trunk = x + lo, see conv3x3.hip)
+    float* R; float* F;      // fp32 blocked-8 skip tensors (RRDB input, global skip), 8 blocks
     float* out_f32;          // EPI_LAST / EPI_DEBUG: [N,cout,H,W] fp32 (may be null)
     uint8_t* out_u8;         // EPI_LAST: [N,H,W,3] u8 (may be null)
     int32_t cout;            // real output channels (EPI_LAST: 3; EPI_DEBUG: Cout)
