@@ -111,6 +111,18 @@ __device__ __forceinline__ f32x4 half4_to_float(u32x2 h) {
 }
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0.2f)); }
 
+// Epilogue stores are unconditional (lanes outside the image write to a trash line), so their
+// count per wave is a compile-time constant and the first wait after an epilogue can allow for
+// them exactly: the ring keeps its R-2 stages in flight across patch boundaries.
+template <int EPI, int CT, int NP>
+struct EpiStores {
+    static constexpr int value = (EPI == EPI_LRELU || EPI == EPI_BODY) ? CT * 2 * NP
+                                 : (EPI == EPI_RDB5)                   ? CT * 4 * NP
+                                 : (EPI == EPI_RDB5_RRDB)              ? CT * 8 * NP
+                                 : (EPI == EPI_FIRST)                  ? CT * 12 * NP
+                                                                       : -1;   // LAST / DEBUG: data-dependent, stay conservative
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vm_barrier() {
     // counted wait for this wave's own LDS-DMA, then the workgroup barrier: past it, every
@@ -204,6 +216,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
         caddr[np] = (uint32_t)(q * 32 + 16 * ((q >> 3) & 1) + 8 * hh);   // half 0; half 1 is at ^16
     }
 
+    char* const trash = p.trash + (size_t)(tid & 255) * 16;   // where out-of-image lanes park their stores
+
     f32x16 acc[CT][NP];
     auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -270,7 +284,10 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                     int j = wave + sl * WAVES;
                     if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
                     const uint32_t dst = lds0 + sl_off + (uint32_t)j * 1024;
-                    glds16<(TRACE || EPI == EPI_DEBUG)>(j < G::PI ? sb : wb, loff[sl], dst);
+                    uint32_t vo = loff[sl];
+                    const char* bp = j < G::PI ? sb : wb;
+                    if (TRACE && (((p.dbg & 1) && j >= G::PI) || ((p.dbg & 2) && j < G::PI))) { vo = lane * 16; bp = (const char*)p.wpack; }
+                    glds16<(TRACE || EPI == EPI_DEBUG)>(bp, vo, dst);
                 }
             }
 #pragma unroll
@@ -364,14 +381,12 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                             v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), t);
                             if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res1[ct][np][g][i]);
                         }
-                        if (EPI == EPI_RDB5_RRDB && ok[np]) *(f32x4*)((char*)p.R + to) = v;
+                        if (EPI == EPI_RDB5_RRDB) *(f32x4*)(ok[np] ? (char*)p.R + to : trash) = v;
                     } else if (EPI == EPI_FIRST) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], p.in_scale), p.bias[cb + i]);
-                        if (ok[np]) {
-                            *(f32x4*)((char*)p.R + to) = v;
-                            *(f32x4*)((char*)p.F + to) = v;
-                        }
+                        *(f32x4*)(ok[np] ? (char*)p.R + to : trash) = v;
+                        *(f32x4*)(ok[np] ? (char*)p.F + to : trash) = v;
                     } else if (EPI == EPI_BODY) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(res0[ct][np][g][i], v[i]);
@@ -414,15 +429,14 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                         const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
                         u32x4 o;
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
-                        if (ok[np])
-                            *(u32x4*)(p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16) = o;
+                        *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
                         if (kTrunk || EPI == EPI_FIRST) {
                             u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
                             const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
                             const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
                             u32x4 ol;
                             ol[0] = q0[0]; ol[1] = q1[0]; ol[2] = q0[1]; ol[3] = q1[1];
-                            if (ok[np]) *(u32x4*)((char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16) = ol;
+                            *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = ol;
                         }
                     }
                 }
@@ -462,14 +476,23 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
     S2SR_STAMP(1);
 
     int k = 0, it_c = 0, st_c = 0;
+    bool after_epi = false;
+    constexpr int NST = EpiStores<EPI, CT, NP>::value;
+    constexpr int NW = G::PW * (R - 2);
     // one ring revolution per loop trip; every condition below is workgroup-uniform
     while (k < S) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (k < S) {
-                // stage k must have landed; stages k+1 .. k+R-2 may stay in flight
-                if (k + (R - 2) < S) wait_vm_barrier<G::PW*(R - 2)>();
-                else wait_vm_barrier<0>();
+                // stage k must have landed; stages k+1 .. k+R-2 (and, right after an epilogue, its
+                // stores, which are younger than all of them) may stay in flight
+                if (k + (R - 2) < S) {
+                    if (NST > 0 && NW + NST < 64 && after_epi) wait_vm_barrier<(NST > 0 ? NW + NST : NW)>();
+                    else wait_vm_barrier<NW>();
+                } else {
+                    wait_vm_barrier<0>();
+                }
+                after_epi = false;
                 S2SR_STAMP(2 + 2 * k);
                 stage_body(smem + r * G::STAGE_BYTES, k + (R - 1) < S, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), r,
                            st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
@@ -479,6 +502,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                     init_acc();
                     st_c = 0;
                     ++it_c;
+                    after_epi = true;
                 }
                 ++k;
             }
@@ -529,6 +553,10 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
 template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     constexpr int R = (CT == 1) ? 5 : 4;
+    if (CT == 1 && EPI == EPI_LRELU && !UP) {
+        static const int waves = env_int("S2SR_CT1_WAVES", 8);
+        if (waves == 4) return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
+    }
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }
 

@@ -61,6 +61,7 @@ struct s2sr_handle {
     std::string err;
     std::vector<ConvW> convs;
     bool has_weights = false;
+    char* d_trash = nullptr;      // parking area for out-of-image epilogue stores
     Workspace ws;
     // scratch device buffers (grown on demand)
     void* d_scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -205,6 +206,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     p.wpack = cw.d_wpack;
     p.bias = cw.d_bias;
     p.nstage = cw.nstage;
+    p.trash = h->d_trash;
     const double px = (double)p.N * p.H * p.W;
     const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
     double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
@@ -363,6 +365,11 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
         delete h;
         return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
     }
+    if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
+        hipStreamDestroy(h->stream);
+        delete h;
+        return fail(nullptr, S2SR_E_HIP, "hipMalloc failed");
+    }
     for (int i = 0; i < F_COUNT; ++i) {
         memset(&h->stats[i], 0, sizeof(s2sr_kstat));
         snprintf(h->stats[i].name, sizeof h->stats[i].name, "%s", kFamName[i]);
@@ -380,6 +387,7 @@ void s2sr_destroy(s2sr_handle* h) {
         if (c.d_bias) hipFree(c.d_bias);
     }
     if (h->ws.base) hipFree(h->ws.base);
+    if (h->d_trash) hipFree(h->d_trash);
     for (int i = 0; i < 6; ++i)
         if (h->d_scratch[i]) hipFree(h->d_scratch[i]);
     for (EvRec& r : h->evs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -749,7 +757,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     ConvParams p{};
     p.src = d_plane; p.src_img = (uint64_t)NB * sblk; p.nstage = NB;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = OHh; p.W = OWw; p.Hp = Hp; p.Wp = Wp; p.sHp = sHp; p.sWp = sWp;
-    p.out_f32 = d_y; p.cout = Cout; p.act = act;
+    p.out_f32 = d_y; p.cout = Cout; p.act = act; p.trash = h->d_trash;
     HIPCHK(h, launch_conv(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -795,7 +803,8 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     ConvParams p{};
     p.src = D0; p.src_img = 12 * blk; p.nstage = cin / 16;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
-    p.T = T; p.R = Rr; p.F = Rr;
+    p.T = T; p.R = Rr; p.F = Rr; p.trash = h->d_trash;
+    p.dbg = getenv("S2SR_DBG") ? atoi(getenv("S2SR_DBG")) : 0;
     int epi;
     if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }
     else { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_RDB5; }

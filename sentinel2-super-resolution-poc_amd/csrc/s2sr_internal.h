@@ -59,7 +59,10 @@ struct ConvParams {
     int32_t cout;            // real output channels (EPI_LAST: 3; EPI_DEBUG: Cout)
     int32_t act;             // EPI_DEBUG: apply lrelu
     float in_scale;          // EPI_FIRST: 1/255 (inputs are fed as exact integers 0..255)
+    char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
+    int32_t dbg;                 // diagnostic only (timing ablations, results wrong): 1 weights DMA from one fixed piece,
+                                 // 2 slab DMA from one fixed piece
 };
 
 // conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.

@@ -13,6 +13,8 @@ for cin, cout in ((64, 32), (160, 32), (192, 64)):
     us, tr = e.bench_conv(N, 256, 256, cin, cout, iters=20, trace_wgs=256)
     fl = 2 * 9 * cin * cout * N * 65536
     print(f"cin={cin} cout={cout} N={N}: {us:.1f} us/launch  {fl/us/1e6:.1f} TF/s")
+    tot = (tr.astype(np.int64)[:, 21] - tr.astype(np.int64)[:, 20])
+    print(f"   TRACE-build kernel time per WG: {np.median(tot[tot>0])/100:.1f} us")
     tr = tr.astype(np.int64)
     tr = tr[tr[:, 0] > 0]
     nst = 9
