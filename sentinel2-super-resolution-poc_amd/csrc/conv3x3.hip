@@ -33,6 +33,13 @@
 
 #include "s2sr_internal.h"
 
+#ifndef S2SR_DMA_LATE
+#define S2SR_DMA_LATE 0
+#endif
+#ifndef S2SR_PREFETCH_D
+#define S2SR_PREFETCH_D 1
+#endif
+
 namespace s2sr {
 
 typedef _Float16 f16;
@@ -264,23 +271,34 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
         // are fetched one step ahead of their first use instead of all up front: no LDS-read
         // bubble behind the barrier.
         f16x8 a[9][CT];
+        constexpr int D = S2SR_PREFETCH_D;   // fragments are requested D steps ahead of their MFMAs ...
+        f16x8 b[D + 1];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) a[0][ct] = *(const f16x8*)(buf + aaddr + ct * 1024);
-        f16x8 b[2];
-        b[0] = *(const f16x8*)(buf + baddr[0][0]);
+        for (int t = 0; t < D; ++t) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) a[t][ct] = *(const f16x8*)(buf + aaddr + (t * CT + ct) * 1024);
+            b[t] = *(const f16x8*)(buf + baddr[t / 3][t % 3]);
+        }
 #pragma unroll
         for (int step = 0; step < G::NBSTEP; ++step) {
             const int s = step / 3, dx = step % 3;
-            if (step + 1 < 9) {
+            if (step + D < 9) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    a[step + 1][ct] = *(const f16x8*)(buf + aaddr + ((step + 1) * CT + ct) * 1024);
+                    a[step + D][ct] = *(const f16x8*)(buf + aaddr + ((step + D) * CT + ct) * 1024);
             }
-            if (step + 1 < G::NBSTEP) b[(step + 1) & 1] = *(const f16x8*)(buf + baddr[(step + 1) / 3][(step + 1) % 3]);
+            if (step + D < G::NBSTEP) b[(step + D) % (D + 1)] = *(const f16x8*)(buf + baddr[(step + D) / 3][(step + D) % 3]);
+            // ... and stay there: without this fence hipcc sinks the reads back next to their use
+            // (lgkmcnt(0/1) before every MFMA), which exposes the LDS latency on every step
+            __builtin_amdgcn_sched_barrier(0);
             if (do_issue) {
 #pragma unroll
                 for (int sl = 0; sl < G::PW; ++sl) {
+#if S2SR_DMA_LATE
+                    if ((G::NBSTEP - 1 - sl > 0 ? G::NBSTEP - 1 - sl : 0) != step) continue;   // DMA rides on the LAST steps
+#else
                     if ((sl < G::NBSTEP - 1 ? sl : G::NBSTEP - 1) != step) continue;
+#endif
                     int j = wave + sl * WAVES;
                     if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
                     const uint32_t dst = lds0 + sl_off + (uint32_t)j * 1024;
@@ -296,7 +314,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                 if (np < 0 || np >= NP) continue;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy * 3 + dx][ct], b[step & 1], acc[ct][np], 0, 0, 0);
+                    acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy * 3 + dx][ct], b[step % (D + 1)], acc[ct][np], 0, 0, 0);
             }
         }
     };
@@ -554,8 +572,9 @@ template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     constexpr int R = (CT == 1) ? 5 : 4;
     if (CT == 1 && EPI == EPI_LRELU && !UP) {
-        static const int waves = env_int("S2SR_CT1_WAVES", 8);
+        static const int waves = env_int("S2SR_CT1_WAVES", 84);
         if (waves == 4) return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
+        if (waves == 84) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);   // 32x32 patch, 3-deep ring
     }
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }

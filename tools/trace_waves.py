@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Per-wave anatomy of one steady-state stage (diagnostic build, S2SR_DBG=4)."""
+import os, sys
+from pathlib import Path
+import numpy as np
+os.environ["S2SR_DBG"] = "4"
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+from s2sr import native
+e = native.Engine(num_block=1)
+for cin, cout in ((160, 32), (192, 64)):
+    us, tr = e.bench_conv(8, 256, 256, cin, cout, iters=5, trace_wgs=256)
+    tr = tr.astype(np.int64)
+    tr = tr[tr[:, 0] > 0]
+    leave5, leave6, end5 = tr[:, 0:8], tr[:, 8:16], tr[:, 16:24]
+    t0 = leave5.min(axis=1, keepdims=True)
+    print(f"cin={cin} cout={cout}: stage 5, cycles relative to first wave leaving the barrier (median over {len(tr)} WGs)")
+    print("   wave:            " + " ".join(f"{w:6d}" for w in range(8)))
+    print("   leave barrier 5: " + " ".join(f"{int(np.median(leave5[:, w] - t0[:, 0])):6d}" for w in range(8)))
+    print("   last MFMA issued:" + " ".join(f"{int(np.median(end5[:, w] - t0[:, 0])):6d}" for w in range(8)))
+    print("   leave barrier 6: " + " ".join(f"{int(np.median(leave6[:, w] - t0[:, 0])):6d}" for w in range(8)))
