@@ -36,7 +36,9 @@ extern "C" {
 
 /* arithmetic of the conv stack */
 #define S2SR_PREC_F16  0   /* fp16 operands, fp32 accumulate on MFMA; fp32 residual trunk  */
-#define S2SR_PREC_F32  1   /* exact fp32 (fp32 MFMA), the parity mode                       */
+#define S2SR_PREC_F16_HP 1 /* same, plus the six convs outside the RRDB trunk (conv_first, conv_body, up1, up2,
+                            * hr, last) computed with split fp16 operands (x_hi,w_hi)+(x_lo,w_hi)+(x_hi,w_lo):
+                            * fp32-class head/tail, ~1e-4 of the fp32 reference at ~1.2x the time            */
 
 typedef struct s2sr_handle s2sr_handle;
 

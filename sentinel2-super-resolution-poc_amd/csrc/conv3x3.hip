@@ -121,9 +121,9 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0
 // Epilogue stores are unconditional (lanes outside the image write to a trash line), so their
 // count per wave is a compile-time constant and the first wait after an epilogue can allow for
 // them exactly: the ring keeps its R-2 stages in flight across patch boundaries.
-template <int EPI, int CT, int NP>
+template <int EPI, int CT, int NP, bool HPO>
 struct EpiStores {
-    static constexpr int value = (EPI == EPI_LRELU || EPI == EPI_BODY) ? CT * 2 * NP
+    static constexpr int value = (EPI == EPI_LRELU || EPI == EPI_BODY) ? CT * (HPO ? 4 : 2) * NP
                                  : (EPI == EPI_RDB5)                   ? CT * 4 * NP
                                  : (EPI == EPI_RDB5_RRDB)              ? CT * 8 * NP
                                  : (EPI == EPI_FIRST)                  ? CT * 12 * NP
@@ -144,7 +144,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
             p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false>
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false>
 __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,8 +196,26 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
     }
 
     // ---- issue cursor: (tile iteration, stage in patch) + uniform base of its patch
-    int it_i = 0, st_i = 0;
+    int it_i = 0, st_i = 0, seg_i = 0, blk_i = 0;
     const char* pbase = nullptr;
+    const char* pbase_lo = nullptr;
+    // source pointer of the stage under the issue cursor, then advance the cursor
+    auto next_src = [&]() __attribute__((always_inline)) -> const char* {
+        if (st_i == 0) {
+            const int tile = it_i * nwg + slot_in_round;
+            const int n = tile / tpi;
+            const int trem = tile - n * tpi;
+            const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+            const int y0 = ty * G::TH, x0 = tx * G::TW;
+            const size_t opix = UP ? (size_t)(y0 >> 1) * p.sWp + (x0 >> 1) : (size_t)y0 * p.sWp + x0;
+            pbase = p.src + (size_t)n * p.src_img + opix * 32;
+            pbase_lo = p.src_lo + (size_t)n * p.lo_img + opix * 32;
+        }
+        const char* sb = (((p.seg_lo_mask >> seg_i) & 1) ? pbase_lo : pbase) + (size_t)blk_i * sblk;
+        if (++blk_i == p.seg_len) { blk_i = 0; ++seg_i; }
+        if (++st_i == NS) { st_i = 0; seg_i = 0; blk_i = 0; ++it_i; }
+        return sb;
+    };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
     // ---- B-fragment addresses inside a slab plane: slab row s (relative to the wave), shift dx
@@ -254,18 +272,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
         const char* sb = nullptr;
         const char* wb = nullptr;
         if (do_issue) {
-            if (st_i == 0) {
-                const int tile = it_i * nwg + slot_in_round;
-                const int n = tile / tpi;
-                const int trem = tile - n * tpi;
-                const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
-                const int y0 = ty * G::TH, x0 = tx * G::TW;
-                const size_t opix = UP ? (size_t)(y0 >> 1) * p.sWp + (x0 >> 1) : (size_t)y0 * p.sWp + x0;
-                pbase = p.src + (size_t)n * p.src_img + opix * 32;
-            }
-            sb = pbase + (size_t)st_i * sblk;
             wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
-            if (++st_i == NS) { st_i = 0; ++it_i; }
+            sb = next_src();
         }
         // A fragment of tap t = dy*3+dx is first needed at B step t (slab row s = dy), so the 9 taps
         // are fetched one step ahead of their first use instead of all up front: no LDS-read
@@ -305,6 +313,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                     uint32_t vo = loff[sl];
                     const char* bp = j < G::PI ? sb : wb;
                     if (TRACE && (((p.dbg & 1) && j >= G::PI) || ((p.dbg & 2) && j < G::PI))) { vo = lane * 16; bp = (const char*)p.wpack; }
+                    if (TRACE && (p.dbg & 8)) continue;   // ablation: no DMA instruction at all
                     glds16<(TRACE || EPI == EPI_DEBUG)>(bp, vo, dst);
                 }
             }
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
                         hpk[g] = __builtin_bit_cast(u32x2, hv);
-                        if (kTrunk || EPI == EPI_FIRST) {
+                        if (kTrunk || EPI == EPI_FIRST || HPO) {
                             f16x4 lv;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) lv[i] = (f16)__fsub_rn(v[i], (float)hv[i]);
@@ -448,7 +457,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
                         u32x4 o;
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                         *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
-                        if (kTrunk || EPI == EPI_FIRST) {
+                        if (kTrunk || EPI == EPI_FIRST || HPO) {
                             u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
                             const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
                             const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
@@ -468,18 +477,8 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < R - 1; ++r) {
             if (r < S) {
-                if (st_i == 0) {
-                    const int tile = it_i * nwg + slot_in_round;
-                    const int n = tile / tpi;
-                    const int trem = tile - n * tpi;
-                    const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
-                    const int y0 = ty * G::TH, x0 = tx * G::TW;
-                    const size_t opix = UP ? (size_t)(y0 >> 1) * p.sWp + (x0 >> 1) : (size_t)y0 * p.sWp + x0;
-                    pbase = p.src + (size_t)n * p.src_img + opix * 32;
-                }
-                const char* sb = pbase + (size_t)st_i * sblk;
                 const char* wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
-                if (++st_i == NS) { st_i = 0; ++it_i; }
+                const char* sb = next_src();
 #pragma unroll
                 for (int sl = 0; sl < G::PW; ++sl) {
                     int j = wave + sl * WAVES;
@@ -495,7 +494,7 @@ __global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
 
     int k = 0, it_c = 0, st_c = 0;
     bool after_epi = false;
-    constexpr int NST = EpiStores<EPI, CT, NP>::value;
+    constexpr int NST = EpiStores<EPI, CT, NP, HPO>::value;
     constexpr int NW = G::PW * (R - 2);
     // one ring revolution per loop trip; every condition below is workgroup-uniform
     while (k < S) {
@@ -540,12 +539,12 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false>
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
-    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE>;
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO>;
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {
@@ -559,6 +558,8 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage % R != 0 || p.nstage < 4))
         return hipErrorInvalidValue;   // the trunk forms pick x out of ring slots 0..3 (see hi_cap)
     ConvParams q = p;
+    if (q.seg_len <= 0) { q.seg_len = q.nstage; q.seg_lo_mask = 0; }
+    if (!q.src_lo) { q.src_lo = q.src; q.lo_img = q.src_img; }
     q.tilesX = (p.W + G::TW - 1) / G::TW;
     q.tilesY = (p.H + G::TH - 1) / G::TH;
     const int ntiles = q.tilesX * q.tilesY * p.N;
@@ -579,7 +580,13 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }
 
-hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, hipStream_t st) {
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_out, hipStream_t st) {
+    if (lo_out) {   // 64-channel outputs that also write their lo half (split-operand mode)
+        if (ct != 2) return hipErrorInvalidValue;
+        if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, true>(p, st);
+        if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, true>(p, st);
+        return hipErrorInvalidValue;
+    }
     if (ct == 1) {
         if (epi == EPI_LRELU && !up) return launch_w<1, EPI_LRELU, false>(p, st);
         if (epi == EPI_LAST && !up) return launch_w<1, EPI_LAST, false>(p, st);
@@ -605,27 +612,33 @@ hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
 //   value = W[cout = ct*32 + (lane&31)][cin = stage*16 + 8*(lane>>5) + j][tap/3][tap%3] * wscale
 // -> each stage's weights are 9*CT contiguous KiB, each KiB is exactly what one A-fragment
 // read (ds_read_b128 at lane*16) wants, so the LDS image is a straight copy of global memory.
-// Missing couts / cins are zero.
+// Missing couts / cins are zero.  Split-operand convs repeat the block per K segment:
+// [w_hi][w_hi][w_lo] (or [w_hi][w_lo]), w_lo = fp16(w - w_hi).
 // ------------------------------------------------------------------------------------------
-size_t conv_wpack_bytes(int cin, int cout) {
+size_t conv_wpack_bytes_seg(int cin, int cout, int nseg) {
     const int ns = (cin + 15) / 16, ct = (cout + 31) / 32;
-    return (size_t)ns * 9 * ct * 1024;
+    return (size_t)nseg * ns * 9 * ct * 1024;
 }
+size_t conv_wpack_bytes(int cin, int cout) { return conv_wpack_bytes_seg(cin, cout, 1); }
 
-void pack_conv_weights(const float* w, int cin, int cout, float wscale, void* dst_host) {
+void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host) {
     const int ns = (cin + 15) / 16, CT = (cout + 31) / 32;
     f16* d = (f16*)dst_host;
-    for (int s = 0; s < ns; ++s)
-        for (int t = 0; t < 9; ++t)
-            for (int ct = 0; ct < CT; ++ct)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int co = ct * 32 + (l & 31);
-                        const int ci = s * 16 + 8 * (l >> 5) + j;
-                        float v = 0.f;
-                        if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * 9 + t] * wscale;
-                        *d++ = (f16)v;
-                    }
+    for (int seg = 0; seg < nseg; ++seg) {
+        const bool lo = (seg == nseg - 1) && nseg > 1;   // the last segment of a split conv carries w_lo
+        for (int s = 0; s < ns; ++s)
+            for (int t = 0; t < 9; ++t)
+                for (int ct = 0; ct < CT; ++ct)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = ct * 32 + (l & 31);
+                            const int ci = s * 16 + 8 * (l >> 5) + j;
+                            float v = 0.f;
+                            if (co < cout && ci < cin) v = w[((size_t)co * cin + ci) * 9 + t];
+                            const f16 hi = (f16)v;
+                            *d++ = lo ? (f16)(v - (float)hi) : hi;
+                        }
+    }
 }
 
 }  // namespace s2sr

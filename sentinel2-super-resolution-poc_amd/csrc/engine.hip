@@ -21,6 +21,7 @@ thread_local std::string g_create_error;
 
 struct ConvW {
     int cin = 0, cout = 0, nstage = 0, ct = 0;
+    int seg_len = 0, seg_lo_mask = 0;   // split-operand convs (precision S2SR_PREC_F16_HP), see ConvParams
     void* d_wpack = nullptr;
     float* d_bias = nullptr;
 };
@@ -42,6 +43,9 @@ struct Workspace {
     float *R = nullptr, *F = nullptr;    // fp32 RRDB skip / global skip (8 blocks of 8)
     // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
+    // lo halves of U0..U3 (split-operand mode only)
+    char *U0lo = nullptr, *U1lo = nullptr, *U2lo = nullptr, *U3lo = nullptr;
+    bool hp = false;
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
     size_t blk1 = 0, blk2 = 0, blk4 = 0;   // bytes of one block plane at 1x / 2x / 4x
 };
@@ -127,13 +131,14 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     Workspace& w = h->ws;
-    if (w.base && w.G >= G && w.H == H && w.W == W) return S2SR_OK;
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP;
+    if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp) return S2SR_OK;
     if (w.base) {
         HIPCHK(h, hipDeviceSynchronize());
         HIPCHK(h, hipFree(w.base));
         w = Workspace();
     }
-    w.G = G; w.H = H; w.W = W;
+    w.G = G; w.H = H; w.W = W; w.hp = hp;
     w.Hp = padded(H); w.Wp = padded(W);
     w.Hp2 = padded(2 * H); w.Wp2 = padded(2 * W);
     w.Hp4 = padded(4 * H); w.Wp4 = padded(4 * W);
@@ -145,6 +150,8 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
                  oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oR = take(g * 8 * w.blk1),
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
+    size_t oU0l = 0, oU1l = 0, oU2l = 0, oU3l = 0;
+    if (hp) { oU0l = take(g * 4 * w.blk1); oU1l = take(g * 4 * w.blk2); oU2l = take(g * 4 * w.blk4); oU3l = take(g * 4 * w.blk4); }
     w.bytes = off;
     HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
@@ -152,6 +159,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.U0 = w.base + oU0;
     w.T = w.base + oT; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
+    if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; }
     return S2SR_OK;
 }
 
@@ -202,10 +210,13 @@ int collect_events(s2sr_handle* h) {
 }
 
 // one conv launch
-int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParams p, int epi, bool up) {
+int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParams p, int epi, bool up,
+             bool lo_out = false) {
     p.wpack = cw.d_wpack;
     p.bias = cw.d_bias;
     p.nstage = cw.nstage;
+    p.seg_len = cw.seg_len;
+    p.seg_lo_mask = cw.seg_lo_mask;
     p.trash = h->d_trash;
     const double px = (double)p.N * p.H * p.W;
     const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
@@ -217,7 +228,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
-    HIPCHK(h, launch_conv(p, cw.ct, epi, up, st));
+    HIPCHK(h, launch_conv(p, cw.ct, epi, up, lo_out, st));
     return S2SR_OK;
 }
 
@@ -253,33 +264,39 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
             if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
             cur ^= 1;
         }
-    {   // conv_body + global skip
+    const bool hp = w.hp;   // split-operand head/tail: inputs as (hi, lo) pairs, outputs write both halves
+    {   // conv_body + global skip; its input is the trunk: hi = x (dense blocks 0..3), lo = trunk lo
         ConvParams p = b;
         p.src = w.D[cur]; p.src_img = 12 * w.blk1; p.dst = w.U0; p.dst_img = 4 * w.blk1;
-        if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false))) return rc;
+        if (hp) { p.src_lo = w.T; p.lo_img = 4 * w.blk1; p.T = w.U0lo; }
+        if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false, hp))) return rc;
     }
     {   // conv_up1 on nearest-2x
         ConvParams p{};
         p.N = n; p.H = 2 * H; p.W = 2 * W; p.Hp = w.Hp2; p.Wp = w.Wp2; p.sHp = w.Hp; p.sWp = w.Wp;
         p.src = w.U0; p.src_img = 4 * w.blk1; p.dst = w.U1; p.dst_img = 4 * w.blk2;
-        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true))) return rc;
+        if (hp) { p.src_lo = w.U0lo; p.lo_img = 4 * w.blk1; p.T = w.U1lo; }
+        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
     }
     {   // conv_up2 on nearest-2x
         ConvParams p{};
         p.N = n; p.H = 4 * H; p.W = 4 * W; p.Hp = w.Hp4; p.Wp = w.Wp4; p.sHp = w.Hp2; p.sWp = w.Wp2;
         p.src = w.U1; p.src_img = 4 * w.blk2; p.dst = w.U2; p.dst_img = 4 * w.blk4;
-        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true))) return rc;
+        if (hp) { p.src_lo = w.U1lo; p.lo_img = 4 * w.blk2; p.T = w.U2lo; }
+        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
     }
     ConvParams hr{};
     hr.N = n; hr.H = 4 * H; hr.W = 4 * W; hr.Hp = w.Hp4; hr.Wp = w.Wp4; hr.sHp = w.Hp4; hr.sWp = w.Wp4;
     {
         ConvParams p = hr;
         p.src = w.U2; p.src_img = 4 * w.blk4; p.dst = w.U3; p.dst_img = 4 * w.blk4;
-        if ((rc = run_conv(h, st, F_HR, h->convs[ci++], p, EPI_LRELU, false))) return rc;
+        if (hp) { p.src_lo = w.U2lo; p.lo_img = 4 * w.blk4; p.T = w.U3lo; }
+        if ((rc = run_conv(h, st, F_HR, h->convs[ci++], p, EPI_LRELU, false, hp))) return rc;
     }
     {
         ConvParams p = hr;
         p.src = w.U3; p.src_img = 4 * w.blk4; p.out_f32 = d_out_f32; p.out_u8 = d_out_u8; p.cout = 3;
+        if (hp) { p.src_lo = w.U3lo; p.lo_img = 4 * w.blk4; }
         if ((rc = run_conv(h, st, F_LAST, h->convs[ci++], p, EPI_LAST, false))) return rc;
     }
     return S2SR_OK;
@@ -300,7 +317,6 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
                 uint8_t* d_out_u8, float* d_out_f32) {
     if (!h->has_weights) return fail(h, S2SR_E_NOWEIGHTS, "s2sr_load_weights has not been called");
     if (B <= 0 || th <= 0 || tw <= 0) return fail(h, S2SR_E_INVALID, "bad batch/tile dims");
-    if (h->cfg.precision != S2SR_PREC_F16) return fail(h, S2SR_E_INVALID, "precision mode not built");
     const int G = group_size(h, B, th, tw);
     int rc = ensure_workspace(h, G, th, tw);
     if (rc) return rc;
@@ -348,7 +364,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     *out = nullptr;
     if (cfg->num_block <= 0 || cfg->num_feat != 64 || cfg->num_grow != 32 || cfg->scale != 4)
         return fail(nullptr, S2SR_E_INVALID, "unsupported net shape (need num_feat=64, num_grow=32, scale=4)");
-    if (cfg->precision != S2SR_PREC_F16 && cfg->precision != S2SR_PREC_F32)
+    if (cfg->precision != S2SR_PREC_F16 && cfg->precision != S2SR_PREC_F16_HP)
         return fail(nullptr, S2SR_E_INVALID, "unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -416,12 +432,20 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     h->has_weights = false;
     const float* pw = blob;
     std::vector<char> tmp;
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP;
+    const size_t nconv = specs.size();
+    size_t idx = 0;
     for (const ConvSpec& s : specs) {
         ConvW cw;
-        cw.cin = s.cin; cw.cout = s.cout; cw.nstage = (s.cin + 15) / 16; cw.ct = (s.cout + 31) / 32;
-        const size_t wb = conv_wpack_bytes(s.cin, s.cout);
+        const int nb = (s.cin + 15) / 16;
+        // split-operand convs: the six outside the RRDB trunk (conv_first, conv_body, up1, up2, hr, last)
+        const bool split = hp && (idx == 0 || idx + 5 >= nconv);
+        const int nseg = !split ? 1 : (idx == 0 ? 2 : 3);   // conv_first's inputs are exact integers: no x_lo
+        cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
+        cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3) ? 0x2 : 0x0;
+        const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
         tmp.resize(wb);
-        pack_conv_weights(pw, s.cin, s.cout, 1.0f, tmp.data());
+        pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data());
         pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
         HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
@@ -431,6 +455,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         HIPCHK(h, hipMalloc((void**)&cw.d_bias, sizeof bias));
         HIPCHK(h, hipMemcpy(cw.d_bias, bias, sizeof bias, hipMemcpyHostToDevice));
         h->convs.push_back(cw);
+        ++idx;
     }
     h->has_weights = true;
     return S2SR_OK;
@@ -746,7 +771,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, hipMalloc((void**)&d_w, wb));
     HIPCHK(h, hipMalloc((void**)&d_b, 64 * 4));
     std::vector<char> wp(wb);
-    pack_conv_weights(weight, Cin, Cout, 1.0f, wp.data());
+    pack_conv_weights(weight, Cin, Cout, 1, wp.data());
     float bb[64] = {0};
     memcpy(bb, bias, Cout * sizeof(float));
     HIPCHK(h, hipMemsetAsync(d_plane, 0, plane_b, st));
@@ -758,7 +783,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     p.src = d_plane; p.src_img = (uint64_t)NB * sblk; p.nstage = NB;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = OHh; p.W = OWw; p.Hp = Hp; p.Wp = Wp; p.sHp = sHp; p.sWp = sWp;
     p.out_f32 = d_y; p.cout = Cout; p.act = act; p.trash = h->d_trash;
-    HIPCHK(h, launch_conv(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, st));
+    HIPCHK(h, launch_conv(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, false, st));
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
@@ -812,9 +837,9 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, st));
+    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, false, st));
     HIPCHK(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, st));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, false, st));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms = 0;

@@ -43,7 +43,14 @@ enum Epilogue : int {
 struct ConvParams {
     const char* src;         // first input block of image 0 (fp16 blocked tensor)
     uint64_t src_img;        // bytes between images of src
-    int32_t nstage;          // 16-channel input blocks consumed (= pipeline stages per patch)
+    int32_t nstage;          // pipeline stages per patch = nseg * seg_len
+    // Split-operand ("hp") convs run the K loop over up to three segments of seg_len blocks that all
+    // accumulate into the same fp32 accumulator: (x_hi,w_hi) (x_lo,w_hi) (x_hi,w_lo).  Bit s of
+    // seg_lo_mask says segment s reads the lo tensor.  Plain convs: seg_len == nstage, mask 0.
+    const char* src_lo;      // lo part of the input (fp16 blocked, same geometry as src), or null
+    uint64_t lo_img;         // bytes between images of src_lo
+    int32_t seg_len;
+    int32_t seg_lo_mask;
     const void* wpack;       // packed fp16 weights (pack_conv_weights)
     const float* bias;       // [64] fp32, zero padded
     int32_t N, H, W;         // output logical dims (images in this launch)
@@ -52,7 +59,8 @@ struct ConvParams {
     int32_t tilesX, tilesY;  // filled by the launcher
     char* dst;               // first OUTPUT block of image 0 (fp16 blocked tensor)
     uint64_t dst_img;        // bytes between images of dst
-    char* T;                 // trunk 'lo' tensor: fp16 blocked-16, 4 blocks (trunk = x + lo, see conv3x3.hip)
+    char* T;                 // 'lo' OUTPUT tensor: fp16 blocked-16, 4 blocks, image stride 4 blocks.  conv_first / conv5:
+                             // the trunk lo (trunk = x + lo); hp convs: lo of their 64-channel output
     float* R; float* F;      // fp32 blocked-8 skip tensors (RRDB input, global skip), 8 blocks
     float* out_f32;          // EPI_LAST / EPI_DEBUG: [N,cout,H,W] fp32 (may be null)
     uint8_t* out_u8;         // EPI_LAST: [N,H,W,3] u8 (may be null)
@@ -62,15 +70,17 @@ struct ConvParams {
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
     int32_t dbg;                 // diagnostic only (timing ablations, results wrong): 1 weights DMA from one fixed piece,
-                                 // 2 slab DMA from one fixed piece
+                                 // 2 slab DMA from one fixed piece, 4 per-wave stamps, 8 no DMA instructions in the loop
 };
 
 // conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.
-hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, hipStream_t st);
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool lo_out, hipStream_t st);
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
-void pack_conv_weights(const float* w, int cin, int cout, float wscale, void* dst_host);
+// nseg 1: [w_hi]; 2: [w_hi][w_lo] (exact-integer inputs: conv_first); 3: [w_hi][w_hi][w_lo]
+void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host);
+size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
 
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);

@@ -21,9 +21,10 @@ ap.add_argument("--blocks", type=int, default=23)
 ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--prof", type=int, default=1)
+ap.add_argument("--hp", type=int, default=0)
 a = ap.parse_args()
 
-e = native.Engine(num_block=a.blocks, group=a.group)
+e = native.Engine(num_block=a.blocks, group=a.group, precision=a.hp)
 e.load_state_dict(synthetic_state_dict(a.blocks, seed=0))
 dev = torch.device("cuda:0")
 x = torch.randint(0, 256, (a.batch, a.size, a.size, 3), dtype=torch.uint8, device=dev)
