@@ -1,0 +1,165 @@
+"""Minimal HTTP harness for the SR handler surface of the reference
+(reference server/app/main.py:192-235 request/response models, :247-368 job runners,
+:371-449 `/api/sr`, :457-541 `/api/wow`).  It exists so that the handler contract -- routes,
+request fields, validation codes, job-table fields and status strings
+`queued -> [fetching] -> processing -> tiling -> completed | failed` -- can be exercised against
+the GPU path in tests; it is NOT a port of the server.  Out of scope and therefore hooks:
+  * imagery fetch (reference smart_fetch.ensure_best_image, network): `fetcher` callback, absent
+    -> a job that needs it fails with a clear message, like any other exception in the reference;
+  * XYZ tiling (reference tiling.process_raster_to_tiles, GDAL subprocesses): `tiler` callback,
+    absent -> the tiling stage is a no-op and `result["tiles_dir"]` is not set.
+"""
+from __future__ import annotations
+
+import threading
+from datetime import datetime
+from pathlib import Path
+from typing import Callable, Optional
+
+from fastapi import BackgroundTasks, FastAPI, HTTPException
+from pydantic import BaseModel
+
+
+class SRRequest(BaseModel):          # main.py:192-197
+    input_file: Optional[str] = None
+    scale: int = 4
+    model: str = "edsr"
+
+
+class WowRequest(BaseModel):         # main.py:200-208
+    input_file: Optional[str] = None
+    enhance_crops: bool = True
+    auto_fetch: bool = True
+    max_age_days: int = 30
+    max_cloud_cover: float = 30.0
+    force_fetch: bool = False
+
+
+class SRResponse(BaseModel):         # main.py:230-235
+    job_id: str
+    status: str
+    message: str
+
+
+def create_app(data_dir: Path, source_dir: Optional[Path] = None,
+               fetcher: Optional[Callable] = None, tiler: Optional[Callable] = None) -> FastAPI:
+    app = FastAPI(title="s2sr SR handler harness")
+    data_dir = Path(data_dir)
+    source_dir = Path(source_dir) if source_dir else data_dir / "source"
+    sr_jobs: dict = {}
+    lock = threading.Lock()          # the reference mutates this dict from worker threads unguarded
+    app.state.sr_jobs = sr_jobs
+
+    def _set(job_id, **kw):
+        with lock:
+            sr_jobs[job_id].update(kw)
+
+    def _latest_tif():
+        tifs = sorted(source_dir.glob("*.tif"), key=lambda x: x.stat().st_mtime, reverse=True)
+        return tifs[0] if tifs else None
+
+    def _tile(result, sub):
+        sr_tif = result["outputs"].get("sr_tif")
+        if tiler and sr_tif and Path(sr_tif).exists():
+            tiles_dir = data_dir / sub
+            tiler(Path(sr_tif), tiles_dir)
+            result["tiles_dir"] = str(tiles_dir)
+
+    def run_sr_job(job_id, input_file, scale, model, output_dir):          # main.py:247-287
+        try:
+            _set(job_id, status="processing", message=f"Applying {model.upper()} x{scale} super-resolution...")
+            from app.farm_sr import process_farm_sr                          # `model` is ignored, as in the reference
+            result = process_farm_sr(input_tif=input_file, output_dir=output_dir, scale=scale)
+            _set(job_id, status="tiling", message="Generating tiles from SR image...")
+            _tile(result, "tiles_sr")
+            _set(job_id, status="completed", message="Super-resolution complete!", result=result)
+        except Exception as e:                                               # noqa: BLE001 -- contract: any error -> failed
+            _set(job_id, status="failed", message=str(e))
+
+    def run_wow_job(job_id, input_file, output_dir, enhance_crops, auto_fetch=True, max_age_days=30,
+                    max_cloud_cover=30.0, force_fetch=False, model="realesrgan_x4"):   # main.py:290-368
+        try:
+            if input_file is None and auto_fetch:
+                _set(job_id, status="fetching",
+                     message=f"Finding best image (last {max_age_days} days, cloud <={max_cloud_cover}%)...")
+                if fetcher is None:
+                    raise RuntimeError("auto_fetch needs the imagery fetcher, which is outside this build; "
+                                       "pass input_file or plug a fetcher into create_app()")
+                input_file, fetch_metadata = fetcher(source_dir, max_age_days, max_cloud_cover, force_fetch)
+                _set(job_id, input_file=str(input_file), fetch_metadata=fetch_metadata)
+            display = {"realesrgan_x4": "Real-ESRGAN x4",
+                       "realesrgan_anime": "Real-ESRGAN Anime 6B (text/plates)"}.get(model, model)
+            _set(job_id, status="processing", message=f"Stage 1/2: {display} (GAN upscaling)...")
+            from app.wow_sr import process_wow_sr
+            result = process_wow_sr(input_tif=input_file, output_dir=output_dir, enhance_crops=enhance_crops, model=model)
+            _set(job_id, status="tiling", message="Generating tiles from WOW SR image...")
+            _tile(result, "tiles_wow")
+            _set(job_id, status="completed", message="WOW Super-resolution complete!", result=result)
+        except Exception as e:                                               # noqa: BLE001
+            _set(job_id, status="failed", message=str(e))
+
+    @app.post("/api/sr", response_model=SRResponse)                          # main.py:371-434
+    def start_super_resolution(request: SRRequest, background_tasks: BackgroundTasks):
+        if request.input_file:
+            input_file = Path(request.input_file)
+        else:
+            input_file = _latest_tif()
+            if input_file is None:
+                raise HTTPException(status_code=404, detail="No GeoTIFF files found. Run fetch first.")
+        if not input_file.exists():
+            raise HTTPException(status_code=404, detail=f"Input file not found: {input_file}")
+        if request.scale not in [2, 3, 4]:
+            raise HTTPException(status_code=400, detail="Scale must be 2, 3, or 4")
+        if request.model not in ["edsr", "espcn", "lapsrn"]:
+            raise HTTPException(status_code=400, detail="Model must be edsr, espcn, or lapsrn")
+        job_id = datetime.now().strftime("%Y%m%d_%H%M%S")
+        output_dir = data_dir / "sr" / job_id
+        output_dir.mkdir(parents=True, exist_ok=True)
+        with lock:
+            sr_jobs[job_id] = {"status": "queued", "message": "Job queued", "input_file": str(input_file),
+                               "scale": request.scale, "model": request.model, "output_dir": str(output_dir),
+                               "created_at": datetime.now().isoformat()}
+        background_tasks.add_task(run_sr_job, job_id, input_file, request.scale, request.model, output_dir)
+        return SRResponse(job_id=job_id, status="queued", message=f"SR job started: {input_file.name} -> x{request.scale}")
+
+    @app.get("/api/sr/{job_id}")                                             # main.py:437-443
+    def get_sr_status(job_id: str):
+        with lock:
+            if job_id not in sr_jobs:
+                raise HTTPException(status_code=404, detail="Job not found")
+            return dict(sr_jobs[job_id])
+
+    @app.get("/api/sr")                                                      # main.py:446-449
+    def list_sr_jobs():
+        with lock:
+            return {"jobs": {k: dict(v) for k, v in sr_jobs.items()}}
+
+    @app.post("/api/wow", response_model=SRResponse)                         # main.py:457-541
+    def start_wow_sr(request: WowRequest, background_tasks: BackgroundTasks):
+        input_file = None
+        if request.input_file:
+            input_file = Path(request.input_file)
+            if not input_file.exists():
+                raise HTTPException(status_code=404, detail=f"Input file not found: {input_file}")
+        elif not request.auto_fetch:
+            input_file = _latest_tif()
+            if input_file is None:
+                raise HTTPException(status_code=404,
+                                    detail="No GeoTIFF files found. Enable auto_fetch=true or run fetch first.")
+        job_id = f"wow_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+        output_dir = data_dir / "wow" / job_id
+        output_dir.mkdir(parents=True, exist_ok=True)
+        with lock:
+            sr_jobs[job_id] = {"status": "queued", "message": "WOW job queued (Real-ESRGAN x4 + Enhanced)",
+                               "input_file": str(input_file) if input_file else "auto_fetch",
+                               "pipeline": "RealESRGAN_x4 + Enhanced", "scale": 4,
+                               "enhance_crops": request.enhance_crops, "auto_fetch": request.auto_fetch,
+                               "max_age_days": request.max_age_days, "max_cloud_cover": request.max_cloud_cover,
+                               "output_dir": str(output_dir), "created_at": datetime.now().isoformat()}
+        background_tasks.add_task(run_wow_job, job_id, input_file, output_dir, request.enhance_crops,
+                                  request.auto_fetch, request.max_age_days, request.max_cloud_cover, request.force_fetch)
+        msg = (f"WOW SR started: {input_file.name} -> Real-ESRGAN x4 + Enhanced" if input_file else
+               f"WOW SR started: auto-fetching best image (last {request.max_age_days}d, cloud <={request.max_cloud_cover}%)")
+        return SRResponse(job_id=job_id, status="queued", message=msg)
+
+    return app

@@ -71,3 +71,27 @@ def test_raster_io_roundtrip(tmp_path):
     img3, _ = rio.read_rgb_u8(tmp_path / "b.tif")
     exp = ((band - band.min()) / (band.max() - band.min()) * 255).astype(np.uint8)
     assert np.array_equal(img3[..., 0], exp) and np.array_equal(img3[..., 0], img3[..., 2])
+
+
+def test_sr_routes_validation(tmp_path):
+    """HTTP-level contract of /api/sr and /api/wow that needs no GPU: 404 / 400 codes, job table."""
+    from fastapi.testclient import TestClient
+    from app.sr_routes import create_app
+    app = create_app(tmp_path / "data")
+    c = TestClient(app)
+    assert c.post("/api/sr", json={}).status_code == 404                       # no GeoTIFF found
+    assert c.post("/api/sr", json={"input_file": str(tmp_path / "nope.tif")}).status_code == 404
+    f = tmp_path / "a.tif"
+    f.write_bytes(b"II*\x00")
+    assert c.post("/api/sr", json={"input_file": str(f), "scale": 5}).status_code == 400
+    assert c.post("/api/sr", json={"input_file": str(f), "model": "swinir"}).status_code == 400
+    assert c.post("/api/wow", json={"auto_fetch": False}).status_code == 404
+    assert c.post("/api/wow", json={"input_file": str(tmp_path / "nope.tif")}).status_code == 404
+    assert c.get("/api/sr/unknown").status_code == 404
+    assert c.get("/api/sr").json() == {"jobs": {}}
+    # auto_fetch without a fetcher: the job is created, then fails with a message (reference: any
+    # exception in the runner becomes status "failed" + str(e))
+    r = c.post("/api/wow", json={})
+    assert r.status_code == 200 and r.json()["status"] == "queued" and r.json()["job_id"].startswith("wow_")
+    st = c.get(f"/api/sr/{r.json()['job_id']}").json()
+    assert st["status"] == "failed" and "fetcher" in st["message"] and st["pipeline"] == "RealESRGAN_x4 + Enhanced"

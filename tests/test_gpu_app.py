@@ -77,3 +77,33 @@ def test_process_wow_and_farm_sr(monkeypatch, tmp_path):
     assert np.array_equal(apply_unsharp_mask(sr_plain, 1.2, 1.5), pp.unsharp(sr_plain, 1.5, 2.2, -1.2))
     assert np.array_equal(enhance_local_contrast(sr_plain, 2.5, 8), pp.local_contrast(sr_plain, 2.5, 8))
     assert np.array_equal(enhance_vegetation(sr_plain), pp.vegetation(sr_plain, 1.3))
+
+
+def test_http_wow_and_sr_jobs(monkeypatch, tmp_path):
+    """POST /api/wow and /api/sr end to end on the GPU path; poll GET /api/sr/{job_id}."""
+    from fastapi.testclient import TestClient
+    from app.sr_routes import create_app
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_x4": 23})
+    rgb = np.random.default_rng(5).integers(0, 256, (20, 28, 3), dtype=np.uint8)
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)})
+    (tmp_path / "data" / "source").mkdir(parents=True)
+    src = tmp_path / "data" / "source" / "s2.tif"
+    rio.write_geotiff_rgb(src, rgb, geo)
+    tiled = []
+    c = TestClient(create_app(tmp_path / "data", tiler=lambda tif, d: tiled.append((tif, d))))
+    r = c.post("/api/wow", json={"auto_fetch": False})           # newest GeoTIFF in source/
+    assert r.status_code == 200 and r.json()["status"] == "queued"
+    st = c.get(f"/api/sr/{r.json()['job_id']}").json()           # TestClient runs background tasks before returning
+    assert st["status"] == "completed", st
+    assert st["result"]["sr_metadata"]["output_size"] == [80, 112] and st["result"]["tiles_dir"].endswith("tiles_wow")
+    out, _ = rio.read_rgb_u8(st["result"]["outputs"]["sr_tif"])
+    assert out.shape == (80, 112, 3)
+    r2 = c.post("/api/sr", json={"input_file": str(src), "scale": 4, "model": "edsr"})
+    st2 = c.get(f"/api/sr/{r2.json()['job_id']}").json()
+    assert st2["status"] == "completed" and st2["result"]["sr_metadata"]["model"] == "RealESRGAN_farm_x4"
+    import time
+    time.sleep(1.1)          # job ids have 1-second resolution (reference main.py:411): avoid the collision
+    r3 = c.post("/api/sr", json={"input_file": str(src), "scale": 2})        # accepted by validation, fails in the job
+    st3 = c.get(f"/api/sr/{r3.json()['job_id']}").json()
+    assert st3["status"] == "failed" and "Unknown model" in st3["message"]
+    assert len(tiled) == 2 and set(c.get("/api/sr").json()["jobs"]) >= {r.json()["job_id"]}
