@@ -86,7 +86,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("S2SR_FORCE_DIST") == "1":   # the env knob rehearses the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
@@ -110,7 +110,7 @@ def main():
     x = torch.from_numpy(tiles_np).to(dev)
     y = torch.empty((B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev)
     y2 = torch.empty_like(y) if a.enhance_crops else None
-    gathered = torch.empty((world * B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) if dist is not None else None
     stream = torch.cuda.current_stream().cuda_stream
     prm = native.pp_wow()
 

@@ -202,3 +202,44 @@ def test_cut_forward_stitch_equals_enhance():
             assert np.array_equal(got, exp), (H, W)
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_configs_vs_oracle():
+    """BASELINE.json sizes: configs[0] one 256x256 tile through the 23-block net, and a 530x600 AOI
+    (3x3 reference windows of 276x276 incl. shifted edge windows) through a 1-block net -- both
+    against the oracle run on this box's host cores."""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    HP = native.PREC_F16_HP
+    rng = np.random.default_rng(77)
+    tile = rng.integers(0, 256, size=(256, 256, 3), dtype=np.uint8)
+    sd23 = ref.to_torch_sd(synthetic_state_dict(23, seed=0))
+    q_ref, f_ref = ref.enhance(tile, sd23, 23, return_float=True)
+    f = engine(23, HP).enhance_f32(tile)
+    err = np.abs(f - f_ref).max()
+    q = engine(23, HP).enhance_u8(tile)
+    d = np.abs(q.astype(np.int16) - q_ref.astype(np.int16))
+    print(f"config[0] 256x256 23 blocks (hp): float err {err:.3e}, u8 identical {np.mean(d == 0):.4f}")
+    assert err <= TOL_HP and d.max() <= 1 and np.mean(d == 0) > 0.99
+    f_fast = engine(23).enhance_f32(tile)
+    assert np.abs(f_fast - f_ref).max() <= TOL_F16
+    img = rng.integers(0, 256, size=(530, 600, 3), dtype=np.uint8)
+    sd1 = ref.to_torch_sd(synthetic_state_dict(1, seed=0))
+    q1_ref, f1_ref = ref.enhance(img, sd1, 1, return_float=True)
+    f1 = engine(1, HP).enhance_f32(img)
+    print(f"530x600 AOI, 9 windows, 1 block (hp): float err {np.abs(f1 - f1_ref).max():.3e}")
+    assert np.abs(f1 - f1_ref).max() <= TOL_HP
+    q1 = engine(1, HP).enhance_u8(img)
+    assert q1.shape == (2120, 2400, 3) and np.abs(q1.astype(np.int16) - q1_ref.astype(np.int16)).max() <= 1
+
+
+def test_whole_image_branch_512_and_odd_shapes():
+    """512x512 is NOT tiled (h*w == tile^2*4 is not '>'); very non-square whole images are legal."""
+    e = engine(1)
+    sd1 = ref.to_torch_sd(synthetic_state_dict(1, seed=0))
+    rng = np.random.default_rng(78)
+    for (H, W) in [(512, 512), (1000, 100), (3, 5), (1, 1)]:
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        _, f_ref = ref.enhance(img, sd1, 1, return_float=True)
+        f = e.enhance_f32(img)
+        assert f.shape == (4 * H, 4 * W, 3)
+        assert np.abs(f - f_ref).max() <= TOL_F16, (H, W)
