@@ -144,8 +144,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
             p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false>
-__global__ void __launch_bounds__(WAVES * 64) conv3x3_f16(const ConvParams p) {
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1>
+__global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -539,12 +539,12 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false>
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R>;
-    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
+    static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
-    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO>;
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC>;
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {
@@ -563,7 +563,7 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     q.tilesX = (p.W + G::TW - 1) / G::TW;
     q.tilesY = (p.H + G::TH - 1) / G::TH;
     const int ntiles = q.tilesX * q.tilesY * p.N;
-    int grid = ncu & ~7;                      // one persistent workgroup per CU
+    int grid = (ncu * OCC) & ~7;              // OCC persistent workgroups per CU
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), G::LDS_BYTES, st, q);
     return hipGetLastError();
@@ -576,6 +576,8 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
         static const int waves = env_int("S2SR_CT1_WAVES", 84);
         if (waves == 4) return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
         if (waves == 84) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);   // 32x32 patch, 3-deep ring
+        if (waves == 82) return launch_t<1, EPI_LRELU, false, 8, 2, 2, false, false, 2>(p, st);   // 2 WGs per CU, double buffer
+        if (waves == 83) return launch_t<1, EPI_LRELU, false, 8, 2, 3, false, false, 1>(p, st);
     }
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }
@@ -603,7 +605,7 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
 }
 
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
-    if (ct == 1) return launch_t<1, EPI_LRELU, false, 8, 2, 5, true>(p, st);
+    if (ct == 1) return launch_t<1, EPI_LRELU, false, 8, 4, 3, true>(p, st);
     return launch_t<2, EPI_RDB5, false, 8, 2, 4, true>(p, st);
 }
 

@@ -837,9 +837,15 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
+    const bool timed_trace = trace && trace_wgs > 0 && getenv("S2SR_TRACE_TIMED");   // time the TRACE build (ablations)
+    if (timed_trace) {
+        HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)256 * 24 * 8));
+        p.trace = d_tr;
+    }
     for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, false, st));
     HIPCHK(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, false, st));
+    for (int i = 0; i < iters; ++i)
+        HIPCHK(h, timed_trace ? launch_conv_trace(p, ct, st) : launch_conv(p, ct, epi, false, false, st));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms = 0;
@@ -847,7 +853,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     *avg_us = ms * 1000.0f / iters;
     if (trace && trace_wgs > 0) {
         const int nwg = 256;
-        HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
+        if (!d_tr) HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
         HIPCHK(h, hipMemset(d_tr, 0, (size_t)nwg * 24 * 8));
         p.trace = d_tr;
         HIPCHK(h, launch_conv_trace(p, ct, st));

@@ -8,7 +8,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
 from s2sr import native
 e = native.Engine(num_block=1)
-for cin, cout in ((160, 32), (192, 64)):
+for cin, cout in ((64, 32), (160, 32), (192, 64)):
     us, tr = e.bench_conv(8, 256, 256, cin, cout, iters=5, trace_wgs=256)
     tr = tr.astype(np.int64)
     tr = tr[tr[:, 0] > 0]
