@@ -150,6 +150,10 @@ int  s2sr_set_profiling(s2sr_handle* h, int32_t on);
 int  s2sr_get_kernel_stats(s2sr_handle* h, s2sr_kstat* out, int32_t cap, int32_t* n);
 int  s2sr_reset_kernel_stats(s2sr_handle* h);
 int  s2sr_synchronize(s2sr_handle* h);
+/* A group (pack + 351 dependent launches) seen twice with the same shapes, buffers and stream
+ * is captured into a hipGraph and replayed afterwards (S2SR_GRAPH=0 disables; the legacy null
+ * stream and profiling runs use direct launches).  Counters since s2sr_create. */
+int  s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays);
 
 /* test hook: one 3x3 conv layer on NCHW fp32 host tensors through the production kernel
  * (upsample != 0 -> nearest-2x on load).  act: 0 none, 1 LeakyReLU(0.2). */

@@ -575,7 +575,10 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     if (CT == 1 && EPI == EPI_LRELU && !UP) {
         static const int waves = env_int("S2SR_CT1_WAVES", 84);
         if (waves == 4) return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
-        if (waves == 84) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);   // 32x32 patch, 3-deep ring
+        // 32x32 patch, 3-deep ring -- unless that leaves most CUs without a patch (single tiles):
+        // then the 16x32 patch spreads the image over twice as many workgroups
+        const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
+        if (waves == 84 && n32 >= 192) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);
         if (waves == 82) return launch_t<1, EPI_LRELU, false, 8, 2, 2, false, false, 2>(p, st);   // 2 WGs per CU, double buffer
         if (waves == 83) return launch_t<1, EPI_LRELU, false, 8, 2, 3, false, false, 1>(p, st);
     }

@@ -56,6 +56,20 @@ struct EvRec {
     double flops, bytes;
 };
 
+// One captured group (pack + the whole layer schedule) for fixed shapes and buffers.  A net is
+// 351 dependent launches; small groups are launch-bound (~15 us per launch against a few us of
+// work), so the second time the same (shape, buffers) group shows up it is captured into a
+// hipGraph and replayed from then on.
+struct GraphEntry {
+    int n = 0, th = 0, tw = 0;
+    const void *in_u8 = nullptr, *in_f32 = nullptr;
+    void *out_u8 = nullptr, *out_f32 = nullptr;
+    hipStream_t st = nullptr;
+    hipGraphExec_t exec = nullptr;   // null until captured
+    bool refused = false;            // capture failed once: stay on direct launches
+    uint64_t last_use = 0;
+};
+
 }  // namespace
 
 struct s2sr_handle {
@@ -76,6 +90,11 @@ struct s2sr_handle {
     std::vector<EvRec> evs;
     std::vector<hipEvent_t> ev_pool;
     s2sr_kstat stats[F_COUNT];
+    // hipGraph replay of repeated groups
+    bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    int64_t graph_replays = 0, graph_captures = 0;
 };
 
 namespace {
@@ -114,10 +133,17 @@ std::vector<ConvSpec> conv_specs(int num_block) {
     return v;
 }
 
+void drop_graphs(s2sr_handle* h) {   // buffers or weights moved: every captured pointer is stale
+    for (GraphEntry& g : h->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
 int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
     if (h->scratch_bytes[slot] >= bytes) return S2SR_OK;
     if (h->d_scratch[slot]) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        drop_graphs(h);
         HIPCHK(h, hipFree(h->d_scratch[slot]));
         h->d_scratch[slot] = nullptr;
         h->scratch_bytes[slot] = 0;
@@ -135,6 +161,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp) return S2SR_OK;
     if (w.base) {
         HIPCHK(h, hipDeviceSynchronize());
+        drop_graphs(h);
         HIPCHK(h, hipFree(w.base));
         w = Workspace();
     }
@@ -324,14 +351,67 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
     const size_t opx = (size_t)16 * th * tw;
     for (int g0 = 0; g0 < B; g0 += G) {
         const int n = (B - g0 < G) ? (B - g0) : G;
-        {
-            Scope sc(h, st, F_PACK, 0.0, (double)n * th * tw * (3.0 + 8.0));
-            if (d_tiles) HIPCHK(h, launch_pack_u8(d_tiles + (size_t)g0 * th * tw * 3, n, th, tw, w.P0, w.Hp, w.Wp, st));
-            else HIPCHK(h, launch_pack_f32_nchw(d_x_f32 + (size_t)g0 * 3 * th * tw, n, 3, th, tw, 255.0f, w.P0, 1, w.Hp, w.Wp, st));
+        const uint8_t* in8 = d_tiles ? d_tiles + (size_t)g0 * th * tw * 3 : nullptr;
+        const float* in32 = d_tiles ? nullptr : d_x_f32 + (size_t)g0 * 3 * th * tw;
+        float* o32 = d_out_f32 ? d_out_f32 + (size_t)g0 * 3 * opx : nullptr;
+        uint8_t* o8 = d_out_u8 ? d_out_u8 + (size_t)g0 * 3 * opx : nullptr;
+        auto enqueue = [&]() -> int {
+            {
+                Scope sc(h, st, F_PACK, 0.0, (double)n * th * tw * (3.0 + 8.0));
+                if (in8) HIPCHK(h, launch_pack_u8(in8, n, th, tw, w.P0, w.Hp, w.Wp, st));
+                else HIPCHK(h, launch_pack_f32_nchw(in32, n, 3, th, tw, 255.0f, w.P0, 1, w.Hp, w.Wp, st));
+            }
+            return run_net(h, st, n, th, tw, o32, o8);
+        };
+        // the legacy null stream cannot be captured; profiling wants its events between launches
+        GraphEntry* ge = nullptr;
+        if (h->graphs_on && h->prof <= 0 && st != nullptr) {
+            for (GraphEntry& g : h->graphs)
+                if (g.n == n && g.th == th && g.tw == tw && g.in_u8 == in8 && g.in_f32 == in32 && g.out_u8 == o8 &&
+                    g.out_f32 == o32 && g.st == st) { ge = &g; break; }
+            if (!ge) {   // first sighting: remember it, launch directly (also warms the per-kernel attributes)
+                if (h->graphs.size() >= 16) {
+                    size_t victim = 0;
+                    for (size_t i = 1; i < h->graphs.size(); ++i)
+                        if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
+                    if (h->graphs[victim].exec) hipGraphExecDestroy(h->graphs[victim].exec);
+                    h->graphs.erase(h->graphs.begin() + victim);
+                }
+                GraphEntry g;
+                g.n = n; g.th = th; g.tw = tw; g.in_u8 = in8; g.in_f32 = in32; g.out_u8 = o8; g.out_f32 = o32; g.st = st;
+                g.last_use = ++h->graph_clock;
+                h->graphs.push_back(g);
+                ge = nullptr;
+            } else if (!ge->exec && !ge->refused) {   // second sighting: capture
+                hipGraph_t graph = nullptr;
+                bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    const int erc = enqueue();
+                    const hipError_t ee = hipStreamEndCapture(st, &graph);
+                    ok = (erc == S2SR_OK) && ee == hipSuccess && graph != nullptr;
+                }
+                if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+                if (graph) hipGraphDestroy(graph);
+                if (!ok) {
+                    (void)hipGetLastError();
+                    ge->exec = nullptr;
+                    ge->refused = true;
+                    ge = nullptr;
+                } else {
+                    ++h->graph_captures;
+                }
+            } else if (ge->refused) {
+                ge = nullptr;
+            }
         }
-        rc = run_net(h, st, n, th, tw, d_out_f32 ? d_out_f32 + (size_t)g0 * 3 * opx : nullptr,
-                     d_out_u8 ? d_out_u8 + (size_t)g0 * 3 * opx : nullptr);
-        if (rc) return rc;
+        if (ge && ge->exec) {
+            ge->last_use = ++h->graph_clock;
+            HIPCHK(h, hipGraphLaunch(ge->exec, st));
+            ++h->graph_replays;
+        } else {
+            rc = enqueue();
+            if (rc) return rc;
+        }
     }
     return S2SR_OK;
 }
@@ -381,6 +461,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
         delete h;
         return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
     }
+    if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->stream);
         delete h;
@@ -398,6 +479,7 @@ void s2sr_destroy(s2sr_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
+    drop_graphs(h);
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
@@ -423,7 +505,8 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         snprintf(b, sizeof b, "weight blob has %zu floats, a %d-block net needs %zu", n_floats, h->cfg.num_block, want);
         return fail(h, S2SR_E_BADBLOB, b);
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipDeviceSynchronize());
+    drop_graphs(h);
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
@@ -739,6 +822,14 @@ int s2sr_get_kernel_stats(s2sr_handle* h, s2sr_kstat* out, int32_t cap, int32_t*
     if (!out) return S2SR_OK;
     if (cap < F_COUNT) return S2SR_E_CAPACITY;
     for (int i = 0; i < F_COUNT; ++i) out[i] = h->stats[i];
+    return S2SR_OK;
+}
+
+int s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays) {
+    if (!h) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (captures) *captures = h->graph_captures;
+    if (replays) *replays = h->graph_replays;
     return S2SR_OK;
 }
 

@@ -81,6 +81,7 @@ _PROTOS = {
     "s2sr_get_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KStat), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
+    "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
@@ -248,6 +249,12 @@ class Engine:
 
     def synchronize(self):
         self._check(self._lib.s2sr_synchronize(self._h), "s2sr_synchronize")
+
+    def graph_stats(self) -> tuple[int, int]:
+        """(groups captured into hipGraphs, graph replays) since the engine was created."""
+        c, r = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.s2sr_graph_stats(self._h, C.byref(c), C.byref(r)), "s2sr_graph_stats")
+        return int(c.value), int(r.value)
 
     # -- test hook --------------------------------------------------------------------------
     def debug_conv(self, x: np.ndarray, weight: np.ndarray, bias: np.ndarray, upsample: bool = False,
