@@ -90,6 +90,8 @@ struct s2sr_handle {
     std::vector<EvRec> evs;
     std::vector<hipEvent_t> ev_pool;
     s2sr_kstat stats[F_COUNT];
+    hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
+    std::vector<hipEvent_t> group_done;
     // hipGraph replay of repeated groups
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     std::vector<GraphEntry> graphs;
@@ -461,8 +463,14 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
         delete h;
         return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
     }
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamDestroy(h->stream);
+        delete h;
+        return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
+    }
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
+        hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
         delete h;
         return fail(nullptr, S2SR_E_HIP, "hipMalloc failed");
@@ -490,6 +498,8 @@ void s2sr_destroy(s2sr_handle* h) {
         if (h->d_scratch[i]) hipFree(h->d_scratch[i]);
     for (EvRec& r : h->evs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : h->group_done) hipEventDestroy(e);
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -592,9 +602,30 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     rc = ensure_scratch(h, 1, ob);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
-    rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0], nullptr, B, th, tw, (uint8_t*)h->d_scratch[1], nullptr);
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, h->stream));
+    // Groups are enqueued one by one with an event after each; the device-to-host copy of group g
+    // runs on the copy stream while group g+1 computes, so only the last group's copy is exposed.
+    const int G = group_size(h, B, th, tw);
+    const size_t tin = (size_t)th * tw * 3, tout = tin * 16;
+    const int ngroups = (B + G - 1) / G;
+    while ((int)h->group_done.size() < ngroups) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->group_done.push_back(e);
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        const int g0 = g * G, n = (B - g0 < G) ? (B - g0) : G;
+        rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0] + g0 * tin, nullptr, n, th, tw,
+                         (uint8_t*)h->d_scratch[1] + g0 * tout, nullptr);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->group_done[g], h->stream));
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        const int g0 = g * G, n = (B - g0 < G) ? (B - g0) : G;
+        HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[g], 0));
+        HIPCHK(h, hipMemcpyAsync(out + g0 * tout, (const uint8_t*)h->d_scratch[1] + g0 * tout, n * tout, hipMemcpyDeviceToHost,
+                                 h->copy_stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return S2SR_OK;
 }
