@@ -424,6 +424,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             const int co = cb + i;
                             if (co >= p.cout || !ok[np]) continue;
                             float o = v[i];
+                            if (EPI == EPI_LAST && g == 0 && p.fold_lo) o = __fadd_rn(o, acc[ct][np][4 + i]);   // + x*w_lo (couts 8..)
                             if (EPI == EPI_DEBUG && p.act) o = lrelu(o);
                             if (p.out_f32) p.out_f32[(((size_t)n * p.cout + co) * p.H + y) * p.W + x] = o;
                             if (EPI == EPI_LAST && p.out_u8) {
@@ -626,9 +627,26 @@ size_t conv_wpack_bytes_seg(int cin, int cout, int nseg) {
 }
 size_t conv_wpack_bytes(int cin, int cout) { return conv_wpack_bytes_seg(cin, cout, 1); }
 
-void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host) {
+void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host, bool fold) {
     const int ns = (cin + 15) / 16, CT = (cout + 31) / 32;
     f16* d = (f16*)dst_host;
+    if (fold) {
+        for (int seg = 0; seg < nseg; ++seg)
+            for (int s = 0; s < ns; ++s)
+                for (int t = 0; t < 9; ++t)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int co = l & 31, ci = s * 16 + 8 * (l >> 5) + j;
+                            f16 o = (f16)0.f;
+                            if (ci < cin && co < cout) o = (f16)w[((size_t)co * cin + ci) * 9 + t];
+                            else if (ci < cin && co >= 8 && co - 8 < cout) {
+                                const float v = w[((size_t)(co - 8) * cin + ci) * 9 + t];
+                                o = (f16)(v - (float)(f16)v);
+                            }
+                            *d++ = o;
+                        }
+        return;
+    }
     for (int seg = 0; seg < nseg; ++seg) {
         const bool lo = (seg == nseg - 1) && nseg > 1;   // the last segment of a split conv carries w_lo
         for (int s = 0; s < ns; ++s)

@@ -22,6 +22,7 @@ thread_local std::string g_create_error;
 struct ConvW {
     int cin = 0, cout = 0, nstage = 0, ct = 0;
     int seg_len = 0, seg_lo_mask = 0;   // split-operand convs (precision S2SR_PREC_F16_HP), see ConvParams
+    bool fold = false;                  // conv_last in hp mode: w_lo folded into idle couts (pack_conv_weights)
     void* d_wpack = nullptr;
     float* d_bias = nullptr;
 };
@@ -246,6 +247,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     p.nstage = cw.nstage;
     p.seg_len = cw.seg_len;
     p.seg_lo_mask = cw.seg_lo_mask;
+    p.fold_lo = cw.fold ? 1 : 0;
     p.trash = h->d_trash;
     const double px = (double)p.N * p.H * p.W;
     const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
@@ -533,12 +535,16 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         const int nb = (s.cin + 15) / 16;
         // split-operand convs: the six outside the RRDB trunk (conv_first, conv_body, up1, up2, hr, last)
         const bool split = hp && (idx == 0 || idx + 5 >= nconv);
-        const int nseg = !split ? 1 : (idx == 0 ? 2 : 3);   // conv_first's inputs are exact integers: no x_lo
+        // conv_first's inputs are exact integers: no x_lo.  conv_last has 29 idle output channels: w_lo
+        // rides in couts 8..10 of both segments (x_hi, x_lo), one pass over x_hi less
+        const bool fold = split && idx + 1 == nconv && s.cout <= 8;
+        const int nseg = !split ? 1 : ((idx == 0 || fold) ? 2 : 3);
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
-        cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3) ? 0x2 : 0x0;
+        cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold) ? 0x2 : 0x0;
         const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
         tmp.resize(wb);
-        pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data());
+        pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
+        cw.fold = fold;
         pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
         HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));

@@ -66,6 +66,7 @@ struct ConvParams {
     uint8_t* out_u8;         // EPI_LAST: [N,H,W,3] u8 (may be null)
     int32_t cout;            // real output channels (EPI_LAST: 3; EPI_DEBUG: Cout)
     int32_t act;             // EPI_DEBUG: apply lrelu
+    int32_t fold_lo;         // EPI_LAST: couts 8..8+cout-1 carry w_lo (pack_conv_weights fold): out[c] = acc[c] + acc[8+c]
     float in_scale;          // EPI_FIRST: 1/255 (inputs are fed as exact integers 0..255)
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
@@ -79,7 +80,9 @@ hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // 
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
 // nseg 1: [w_hi]; 2: [w_hi][w_lo] (exact-integer inputs: conv_first); 3: [w_hi][w_hi][w_lo]
-void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host);
+// fold (cout <= 8 only): every segment is [w_hi at couts 0.., w_lo at couts 8..] so a conv with idle
+// output channels gets x*w_hi and x*w_lo from one pass over x (conv_last in hp mode: 2 segments, x_hi and x_lo)
+void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host, bool fold = false);
 size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
 
 // data-movement kernels (pack.hip)
