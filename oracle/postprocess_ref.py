@@ -195,8 +195,14 @@ def hsv2rgb_u8(hsv: np.ndarray) -> np.ndarray:
 # CLAHE
 # ------------------------------------------------------------------------------------------
 def _reflect101(idx, n):
-    idx = np.abs(idx)
-    return np.where(idx >= n, 2 * (n - 1) - idx, idx)
+    """BORDER_REFLECT_101 index map (cv::borderInterpolate: reflect until inside, so images
+    smaller than the border bounce more than once; a 1-pixel axis maps everything to 0)."""
+    idx = np.abs(np.asarray(idx))
+    if n == 1:
+        return np.zeros_like(idx)
+    period = 2 * (n - 1)
+    idx = idx % period
+    return np.where(idx >= n, period - idx, idx)
 
 
 def clahe_u8(src: np.ndarray, clip_limit: float, grid: int) -> np.ndarray:

@@ -105,11 +105,25 @@ hipError_t get_tables(PPTables** out) {
 }
 
 // ---- device helpers -------------------------------------------------------------------------
+// The colour tables are 14 KiB of random-access lookups, a dozen per pixel: every workgroup copies
+// them into LDS once (global lookups cost a TA pass per distinct line per wave).
+__device__ __forceinline__ const PPTables* stage_tables(const PPTables* __restrict__ t, PPTables* s_t) {
+    static_assert(sizeof(PPTables) % 4 == 0, "dword copy");
+    const uint32_t* src = (const uint32_t*)t;
+    uint32_t* dst = (uint32_t*)s_t;
+    for (int i = threadIdx.x; i < (int)(sizeof(PPTables) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return s_t;
+}
+
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 __device__ __forceinline__ int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
-__device__ __forceinline__ int reflect101(int i, int n) {
-    i = i < 0 ? -i : i;
-    return i >= n ? 2 * (n - 1) - i : i;
+__device__ __forceinline__ int reflect101(int i, int n) {   // BORDER_REFLECT_101, any number of bounces
+    if ((unsigned)i < (unsigned)n) return i;
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i = (i < 0 ? -i : i) % period;
+    return i >= n ? period - i : i;
 }
 
 __device__ __forceinline__ void rgb2lab(const PPTables* __restrict__ t, int r, int g, int b, int& L, int& A, int& B) {
@@ -147,13 +161,13 @@ __device__ __forceinline__ void lab2rgb(const PPTables* __restrict__ t, int L, i
     b = t->inv_gamma[v2];
 }
 
-__device__ __forceinline__ void rgb2hsv(const PPTables* __restrict__ t, int r, int g, int b, int& h, int& s, int& v) {
-    v = max(max(r, g), b);
+__device__ __forceinline__ void rgb2hsv(const int32_t* __restrict__ div, int r, int g, int b, int& h, int& s, int& v) {
+    v = max(max(r, g), b);     // div = sdiv[256] | hdiv180[256]
     const int vmin = min(min(r, g), b);
     const int diff = v - vmin;
-    s = (diff * t->sdiv[v] + (1 << 11)) >> 12;
+    s = (diff * div[v] + (1 << 11)) >> 12;
     int hh = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-    hh = (hh * t->hdiv180[diff] + (1 << 11)) >> 12;
+    hh = (hh * div[256 + diff] + (1 << 11)) >> 12;
     hh += hh < 0 ? 180 : 0;
     h = clamp255(hh);
 }
@@ -198,23 +212,24 @@ struct ClaheGeom {
     int eh, ew;      // padded ("ext") image size
     int clip;        // absolute clip limit, 0 = off
     float lut_scale;
+    int split;       // clahe_hist: workgroups (row bands) per CLAHE tile
 };
 
 // ---- kernel 1: per-tile L histograms --------------------------------------------------------
 // grid.x = B * grid*grid * SPLIT ; every workgroup takes a horizontal band of one CLAHE tile.
-constexpr int HIST_SPLIT = 8;
 __global__ void __launch_bounds__(256) clahe_hist_kernel(const uint8_t* __restrict__ rgb, ClaheGeom gm,
                                                          const PPTables* __restrict__ t, uint32_t* __restrict__ hist) {
     __shared__ uint32_t sh[256];
+    __shared__ PPTables s_t;
     sh[threadIdx.x] = 0;
-    __syncthreads();
+    t = stage_tables(t, &s_t);
     const int ntile = gm.grid * gm.grid;
     int id = blockIdx.x;
-    const int part = id % HIST_SPLIT; id /= HIST_SPLIT;
+    const int part = id % gm.split; id /= gm.split;
     const int tile = id % ntile;
     const int img = id / ntile;
     const int ty = tile / gm.grid, tx = tile % gm.grid;
-    const int rows_per = (gm.th + HIST_SPLIT - 1) / HIST_SPLIT;
+    const int rows_per = (gm.th + gm.split - 1) / gm.split;
     const int r0 = part * rows_per, r1 = min(gm.th, r0 + rows_per);
     const uint8_t* base = rgb + (size_t)img * gm.H * gm.W * 3;
     const int npx = (r1 - r0) * gm.tw;
@@ -272,6 +287,8 @@ __global__ void __launch_bounds__(256) clahe_lut_kernel(const uint32_t* __restri
 __global__ void __launch_bounds__(256) clahe_apply_kernel(const uint8_t* __restrict__ rgb, ClaheGeom gm, int B,
                                                           const PPTables* __restrict__ t,
                                                           const uint8_t* __restrict__ lut, uint8_t* __restrict__ out) {
+    __shared__ PPTables s_t;
+    t = stage_tables(t, &s_t);
     const size_t npx = (size_t)gm.H * gm.W, total = npx * B;
     const float inv_tw = 1.0f / (float)gm.tw, inv_th = 1.0f / (float)gm.th;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -301,6 +318,71 @@ __global__ void __launch_bounds__(256) clahe_apply_kernel(const uint8_t* __restr
     }
 }
 
+// ---- kernel 3b: same, 4 consecutive pixels (12 bytes = 3 dwords) per thread ----------------------
+// Needs 4-byte aligned tensors; lanes read and write 12 contiguous bytes each, so a wave moves 768
+// contiguous bytes per instruction instead of 64 scattered single bytes.
+__device__ __forceinline__ void clahe_pixel(const PPTables* __restrict__ t, const ClaheGeom& gm, const uint8_t* __restrict__ lut_img,
+                                            float inv_tw, float inv_th, int y, int x, int& r, int& g, int& b) {
+    int L, A, Bc;
+    rgb2lab(t, r, g, b, L, A, Bc);
+    const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
+    int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+    const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
+    const float xa1 = 1.0f - xa, ya1 = 1.0f - ya;
+    const int tx2 = min(tx1 + 1, gm.grid - 1), ty2 = min(ty1 + 1, gm.grid - 1);
+    tx1 = max(tx1, 0);
+    ty1 = max(ty1, 0);
+    const uint8_t* lb = lut_img + L;
+    const float l11 = lb[(ty1 * gm.grid + tx1) * 256], l12 = lb[(ty1 * gm.grid + tx2) * 256];
+    const float l21 = lb[(ty2 * gm.grid + tx1) * 256], l22 = lb[(ty2 * gm.grid + tx2) * 256];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    lab2rgb(t, sat_round(res), A, Bc, r, g, b);
+}
+
+__global__ void __launch_bounds__(256) clahe_apply4_kernel(const uint8_t* __restrict__ rgb, ClaheGeom gm, int B,
+                                                           const PPTables* __restrict__ t,
+                                                           const uint8_t* __restrict__ lut, uint8_t* __restrict__ out) {
+    __shared__ PPTables s_t;
+    t = stage_tables(t, &s_t);
+    const uint32_t npx = (uint32_t)gm.H * gm.W;
+    const uint32_t total = npx * (uint32_t)B;            // launcher guarantees < 2^32
+    const uint32_t ngroups = (total + 3) / 4;
+    const float inv_tw = 1.0f / (float)gm.tw, inv_th = 1.0f / (float)gm.th;
+    for (uint32_t gidx = blockIdx.x * blockDim.x + threadIdx.x; gidx < ngroups; gidx += gridDim.x * blockDim.x) {
+        const uint32_t p0 = 4 * gidx;
+        const size_t off = (size_t)p0 * 3;
+        const uint32_t n = min(4u, total - p0);
+        uint32_t w[3] = {0, 0, 0};
+        if (n == 4) {
+            const uint32_t* src = (const uint32_t*)(rgb + off);
+            w[0] = src[0]; w[1] = src[1]; w[2] = src[2];
+        } else {
+            for (uint32_t k = 0; k < 3 * n; ++k) w[k >> 2] |= (uint32_t)rgb[off + k] << (8 * (k & 3));
+        }
+        uint32_t img = p0 / npx;
+        const uint32_t rem = p0 - img * npx;
+        uint32_t y = rem / gm.W, x = rem - y * gm.W;
+        uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int bi = 3 * k;
+            int r = (w[bi >> 2] >> (8 * (bi & 3))) & 255, g = (w[(bi + 1) >> 2] >> (8 * ((bi + 1) & 3))) & 255,
+                b = (w[(bi + 2) >> 2] >> (8 * ((bi + 2) & 3))) & 255;
+            if ((uint32_t)k < n) clahe_pixel(t, gm, lut + (size_t)img * gm.grid * gm.grid * 256, inv_tw, inv_th, (int)y, (int)x, r, g, b);
+            o[bi >> 2] |= (uint32_t)r << (8 * (bi & 3));
+            o[(bi + 1) >> 2] |= (uint32_t)g << (8 * ((bi + 1) & 3));
+            o[(bi + 2) >> 2] |= (uint32_t)b << (8 * ((bi + 2) & 3));
+            if (++x == (uint32_t)gm.W) { x = 0; if (++y == (uint32_t)gm.H) { y = 0; ++img; } }
+        }
+        if (n == 4) {
+            uint32_t* dst = (uint32_t*)(out + off);
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        } else {
+            for (uint32_t k = 0; k < 3 * n; ++k) out[off + k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+        }
+    }
+}
+
 // ---- kernel 4: unsharp mask + vegetation boost ----------------------------------------------
 constexpr int ST = 32;          // output tile edge
 constexpr int MAXR = 8;         // max Gaussian radius (ksize <= 17)
@@ -317,6 +399,8 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
                                                           const PPTables* __restrict__ t, uint8_t* __restrict__ out) {
     __shared__ uint8_t s_in[(ST + 2 * MAXR) * (ST + 2 * MAXR) * 3];
     __shared__ uint16_t s_h[(ST + 2 * MAXR) * ST * 3];
+    __shared__ int32_t s_div[512];   // sdiv | hdiv180
+    for (int i = threadIdx.x; i < 512; i += 256) s_div[i] = i < 256 ? t->sdiv[i] : t->hdiv180[i - 256];
     const int tilesX = (sp.W + ST - 1) / ST, tilesY = (sp.H + ST - 1) / ST;
     int id = blockIdx.x;
     const int tx = id % tilesX; id /= tilesX;
@@ -367,7 +451,7 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
         }
         if (sp.do_veg) {
             int h, s, v;
-            rgb2hsv(t, px[0], px[1], px[2], h, s, v);
+            rgb2hsv(s_div, px[0], px[1], px[2], h, s, v);
             if (h > sp.hue_lo && h < sp.hue_hi) {
                 // float32 S*gain, clip to [0,255], astype(uint8) == truncation (wow_sr.py:204-207)
                 float fs = (float)s * sp.sat_gain;
@@ -380,6 +464,141 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
         o[0] = (uint8_t)px[0];
         o[1] = (uint8_t)px[1];
         o[2] = (uint8_t)px[2];
+    }
+}
+
+// ---- kernel 4b: the same stage for the radii the reference uses (3, 4, 5), restructured ----------
+// The generic kernel above spends its time in LDS byte reads (2r+1 per output and pass).  Here the
+// tile is 64x32, the staged pixels are de-interleaved into channel planes so a run of consecutive
+// x is a run of consecutive bytes, and both passes slide a register window: the horizontal pass
+// makes 8 outputs from three 8-byte reads, the vertical pass 2x4 outputs per channel from 4+2R
+// dword reads.  Interior tiles are staged with aligned dword loads (one wave per row).
+constexpr int SW = 64, SH = 32, SPITCH = 96;
+template <int R>
+__global__ void __launch_bounds__(256) sharpen_veg_kernel_r(const uint8_t* __restrict__ in, SharpParams sp, size_t total_bytes,
+                                                            const PPTables* __restrict__ t, uint8_t* __restrict__ out) {
+    constexpr int EH = SH + 2 * R, EW = SW + 2 * R, NT = 2 * R + 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[3 * EH * SPITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[3 * EH * SW];
+    __shared__ int32_t s_div[512];   // sdiv | hdiv180
+    for (int i = threadIdx.x; i < 512; i += 256) s_div[i] = i < 256 ? t->sdiv[i] : t->hdiv180[i - 256];
+    const int tilesX = (sp.W + SW - 1) / SW, tilesY = (sp.H + SH - 1) / SH;
+    int id = blockIdx.x;
+    const int tx = id % tilesX; id /= tilesX;
+    const int ty = id % tilesY;
+    const int img = id / tilesY;
+    const uint8_t* src = in + (size_t)img * sp.H * sp.W * 3;
+    uint8_t* dst = out + (size_t)img * sp.H * sp.W * 3;
+    const int y0 = ty * SH, x0 = tx * SW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (x0 - R >= 0 && x0 + SW - 1 + R < sp.W) {
+        // interior in x: each staged row is EW*3 contiguous bytes of one image row
+        for (int ly = wave; ly < EH; ly += 4) {
+            int sy = reflect101(min(y0 + ly - R, sp.H - 1 + R), sp.H);
+            sy = min(max(sy, 0), sp.H - 1);
+            const uintptr_t a = (uintptr_t)(src + ((size_t)sy * sp.W + (x0 - R)) * 3);
+            const int mis = (int)(a & 3);
+            const uintptr_t al = a - mis + 4 * (uintptr_t)lane;
+            if (4 * lane < mis + EW * 3) {
+                uint32_t d = 0;
+                if (al >= (uintptr_t)in && al + 4 <= (uintptr_t)in + total_bytes) {
+                    d = *(const uint32_t*)al;
+                } else {
+                    for (int k = 0; k < 4; ++k)
+                        if (al + k >= (uintptr_t)in && al + k < (uintptr_t)in + total_bytes) d |= (uint32_t)(*(const uint8_t*)(al + k)) << (8 * k);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int b = 4 * lane + k - mis;
+                    if (b >= 0 && b < EW * 3) {
+                        const int px = b / 3, c = b - 3 * px;
+                        s_in[(c * EH + ly) * SPITCH + px] = (uint8_t)(d >> (8 * k));
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < EH * EW; i += 256) {
+            const int ly = i / EW, lx = i % EW;
+            int sy = reflect101(min(y0 + ly - R, sp.H - 1 + R), sp.H), sx = reflect101(min(x0 + lx - R, sp.W - 1 + R), sp.W);
+            sy = min(max(sy, 0), sp.H - 1);   // only reachable for images smaller than the kernel radius
+            sx = min(max(sx, 0), sp.W - 1);
+            const uint8_t* p = src + ((size_t)sy * sp.W + sx) * 3;
+            s_in[(0 * EH + ly) * SPITCH + lx] = p[0];
+            s_in[(1 * EH + ly) * SPITCH + lx] = p[1];
+            s_in[(2 * EH + ly) * SPITCH + lx] = p[2];
+        }
+    }
+    __syncthreads();
+    // horizontal pass: item = (channel, row, group of 8 x)
+    for (int it = threadIdx.x; it < 3 * EH * (SW / 8); it += 256) {
+        const int j = it % (SW / 8), cr = it / (SW / 8);   // cr = c*EH + row
+        const uint8_t* rowp = s_in + cr * SPITCH + 8 * j;
+        uint32_t w[6];
+        const uint2 q0 = *(const uint2*)(rowp), q1 = *(const uint2*)(rowp + 8), q2 = *(const uint2*)(rowp + 16);
+        w[0] = q0.x; w[1] = q0.y; w[2] = q1.x; w[3] = q1.y; w[4] = q2.x; w[5] = q2.y;
+        uint32_t o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int b = i + k;
+                acc += (uint32_t)sp.taps[k] * ((w[b >> 2] >> (8 * (b & 3))) & 255u);
+            }
+            o[i] = acc;   // <= 255*256: fits 16 bits
+        }
+        uint4 pk;
+        pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16); pk.z = o[4] | (o[5] << 16); pk.w = o[6] | (o[7] << 16);
+        *(uint4*)(s_h + (size_t)cr * SW + 8 * j) = pk;
+    }
+    __syncthreads();
+    // vertical pass + weighted add + vegetation boost: thread = (x pair, 4 rows)
+    const int xp = threadIdx.x & 31, yq = threadIdx.x >> 5;
+    int res[4][2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t col[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) col[k] = *(const uint32_t*)(s_h + (size_t)(c * EH + 4 * yq + k) * SW + 2 * xp);
+#pragma unroll
+        for (int ry = 0; ry < 4; ++ry) {
+            uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                a0 += (uint32_t)sp.taps[k] * (col[ry + k] & 0xffffu);
+                a1 += (uint32_t)sp.taps[k] * (col[ry + k] >> 16);
+            }
+            const int b0 = clamp255((int)((a0 + (1u << 15)) >> 16)), b1 = clamp255((int)((a1 + (1u << 15)) >> 16));
+            const uint8_t* cp = s_in + (c * EH + 4 * yq + ry + R) * SPITCH + 2 * xp + R;
+            res[ry][0][c] = sat_round((float)cp[0] * sp.w_img + (float)b0 * sp.w_blur);
+            res[ry][1][c] = sat_round((float)cp[1] * sp.w_img + (float)b1 * sp.w_blur);
+        }
+    }
+#pragma unroll
+    for (int ry = 0; ry < 4; ++ry) {
+        const int y = y0 + 4 * yq + ry;
+#pragma unroll
+        for (int xx = 0; xx < 2; ++xx) {
+            int px[3] = {res[ry][xx][0], res[ry][xx][1], res[ry][xx][2]};
+            if (sp.do_veg) {
+                int h, sa, v;
+                rgb2hsv(s_div, px[0], px[1], px[2], h, sa, v);
+                if (h > sp.hue_lo && h < sp.hue_hi) {
+                    float fs = (float)sa * sp.sat_gain;
+                    fs = fminf(fmaxf(fs, 0.f), 255.f);
+                    sa = (int)fs;
+                }
+                hsv2rgb(h, sa, v, px[0], px[1], px[2]);
+            }
+            const int x = x0 + 2 * xp + xx;
+            if (y < sp.H && x < sp.W) {   // byte stores: measured faster than staging rows in LDS for dword stores
+                uint8_t* o = dst + ((size_t)y * sp.W + x) * 3;
+                o[0] = (uint8_t)px[0];
+                o[1] = (uint8_t)px[1];
+                o[2] = (uint8_t)px[2];
+            }
+        }
     }
 }
 
@@ -447,16 +666,25 @@ hipError_t launch_postprocess(const uint8_t* d_rgb, int B, int H, int W, const s
     const bool s1 = prm.stages & 1, s2 = prm.stages & 2, s3 = prm.stages & 4;
     const uint8_t* cur = d_rgb;
     if (s1) {
-        const ClaheGeom g = clahe_geom(H, W, prm);
+        ClaheGeom g = clahe_geom(H, W, prm);
         if (g.th <= 0 || g.tw <= 0) return hipErrorInvalidValue;
+        // enough workgroups to fill 256 CUs, but each one stages 14 KiB of tables: keep them fat
+        g.split = tiles >= 2048 ? 1 : (tiles >= 1024 ? 2 : (tiles >= 512 ? 4 : 8));
         e = hipMemsetAsync(d_hist, 0, tiles * 256 * 4, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(clahe_hist_kernel, dim3((unsigned)(tiles * HIST_SPLIT)), dim3(256), 0, st, cur, g, t, d_hist);
+        hipLaunchKernelGGL(clahe_hist_kernel, dim3((unsigned)(tiles * g.split)), dim3(256), 0, st, cur, g, t, d_hist);
         hipLaunchKernelGGL(clahe_lut_kernel, dim3((unsigned)tiles), dim3(256), 0, st, d_hist, g, d_lut);
         uint8_t* o = (s2 || s3) ? d_tmp : d_out;
         const size_t total = (size_t)B * H * W;
-        const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-        hipLaunchKernelGGL(clahe_apply_kernel, dim3(grid), dim3(256), 0, st, cur, g, B, t, d_lut, o);
+        const unsigned grid = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        const bool aligned = (((uintptr_t)cur | (uintptr_t)o) & 3) == 0 && total < (1ull << 32);
+        if (aligned) {
+            const size_t ng = (total + 3) / 4;
+            const unsigned grid4 = (unsigned)((ng + 255) / 256 > 2048 ? 2048 : (ng + 255) / 256);
+            hipLaunchKernelGGL(clahe_apply4_kernel, dim3(grid4), dim3(256), 0, st, cur, g, B, t, d_lut, o);
+        } else {
+            hipLaunchKernelGGL(clahe_apply_kernel, dim3(grid), dim3(256), 0, st, cur, g, B, t, d_lut, o);
+        }
         cur = o;
     }
     if (s2 || s3) {
@@ -467,7 +695,12 @@ hipError_t launch_postprocess(const uint8_t* d_rgb, int B, int H, int W, const s
         sp.w_img = prm.w_img; sp.w_blur = prm.w_blur;
         sp.do_veg = s3 ? 1 : 0; sp.hue_lo = prm.hue_lo; sp.hue_hi = prm.hue_hi; sp.sat_gain = prm.sat_gain;
         const unsigned grid = (unsigned)(((W + ST - 1) / ST) * ((H + ST - 1) / ST) * B);
-        hipLaunchKernelGGL(sharpen_veg_kernel, dim3(grid), dim3(256), 0, st, cur, sp, t, d_out);
+        const unsigned grid_r = (unsigned)(((W + SW - 1) / SW) * ((H + SH - 1) / SH) * B);
+        const size_t total_bytes = (size_t)B * H * W * 3;
+        if (sp.radius == 4) hipLaunchKernelGGL(sharpen_veg_kernel_r<4>, dim3(grid_r), dim3(256), 0, st, cur, sp, total_bytes, t, d_out);
+        else if (sp.radius == 5) hipLaunchKernelGGL(sharpen_veg_kernel_r<5>, dim3(grid_r), dim3(256), 0, st, cur, sp, total_bytes, t, d_out);
+        else if (sp.radius == 3) hipLaunchKernelGGL(sharpen_veg_kernel_r<3>, dim3(grid_r), dim3(256), 0, st, cur, sp, total_bytes, t, d_out);
+        else hipLaunchKernelGGL(sharpen_veg_kernel, dim3(grid), dim3(256), 0, st, cur, sp, t, d_out);
     } else if (!s1) {
         e = hipMemcpyAsync(d_out, d_rgb, (size_t)B * H * W * 3, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;

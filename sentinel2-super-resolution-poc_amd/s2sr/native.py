@@ -97,6 +97,13 @@ def load_library():
     if not LIB_PATH.exists():
         raise S2srError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C {LIB_PATH.parent}`.  There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime; whichever HSA runtime is mapped first
+    # serves both HIP runtimes of the process.  torch's must come first (the other order leaves
+    # torch with "No HIP GPUs are available"), so pull torch in before dlopen when it exists.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)          # AttributeError here == ABI drift, let it surface

@@ -79,3 +79,37 @@ def test_wow_on_sr_sized_image(eng):
     img = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
     img[..., 1] = np.maximum(img[..., 1], 90)
     assert np.array_equal(eng.postprocess_u8(img, native.pp_wow()), pp.enhance_for_crops(img))
+
+
+def test_radius3_tiny_and_misaligned_batch(eng):
+    """The restructured sharpen kernel: radius 3 (sigma 1.0), an image smaller than the blur radius,
+    and a batch whose images start at odd byte offsets (dword staging of interior tiles)."""
+    import torch
+
+    P = native.PPParams
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (70, 210, 3), dtype=np.uint8)
+    prm = P(3.0, 8, 1.0, 2.5, -1.5, 35, 85, 1.3, 2)          # apply_unsharp_mask(strength=1.5, radius=1.0)
+    assert np.array_equal(eng.postprocess_u8(img, prm), pp.unsharp(img, 1.0, 2.5, -1.5))
+    tiny = rng.integers(0, 256, (3, 5, 3), dtype=np.uint8)
+    for sigma, a, b in ((1.2, 1.4, -0.4), (1.5, 2.2, -1.2)):
+        prm = P(2.5, 8, sigma, a, b, 35, 85, 1.2, 2)
+        assert np.array_equal(eng.postprocess_u8(tiny, prm), pp.unsharp(tiny, sigma, a, b))
+    batch = rng.integers(0, 256, (3, 35, 203, 3), dtype=np.uint8)   # 21315 bytes per image: odd offsets
+    batch[..., 1] = np.maximum(batch[..., 1], 100)
+    x = torch.from_numpy(batch).cuda()
+    y = torch.empty_like(x)
+    for prm, fn in ((native.pp_wow(), pp.enhance_for_crops), (native.pp_farm(), pp.farm_postprocess)):
+        eng.postprocess_batch_u8_dev(x.data_ptr(), 3, 35, 203, prm, y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(got[i], fn(batch[i])), f"image {i}"
+    # a view that starts 1 byte into its buffer: the first dword of the first row straddles the start
+    flat = torch.empty(1 + 35 * 203 * 3, dtype=torch.uint8, device="cuda")
+    flat[1:] = torch.from_numpy(batch[0].ravel()).cuda()
+    out = torch.empty(35 * 203 * 3, dtype=torch.uint8, device="cuda")
+    eng.postprocess_batch_u8_dev(flat.data_ptr() + 1, 1, 35, 203, native.pp_wow(), out.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(35, 203, 3), pp.enhance_for_crops(batch[0]))
