@@ -29,6 +29,7 @@
 //     loader's source offsets (>>1) and never materialised.
 //   * Inside a stage the 9 A fragments stay in registers and every B fragment (slab row s,
 //     column shift dx) is read ONCE and used for all kernel rows dy with 0 <= s-dy < NP.
+#include <math.h>
 #include <stdlib.h>
 
 #include "s2sr_internal.h"
@@ -49,6 +50,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -144,9 +146,17 @@ __device__ __forceinline__ void wait_vm_barrier() {
             p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1>
+// F8 (split-operand consumers, S2SR_PREC_F16_HP): a patch is 8 stages -- 4 fp16 blocks of x_hi
+// against w_hi, then 4 fp8 (e4m3) planes of 32 channels: [x_lo*2^11 | x_hi] against
+// [w_hi | w_lo*2^11], two planes per v_mfma_scale_f32_32x32x64_f8f6f4 (lanes 0-31 take their 32 K
+// bytes from the first plane, lanes 32-63 from the second) with a constant 2^-11 block scale: the
+// correction terms run at twice the fp16 rate on half the bytes.  An fp8 plane is 32 B per pixel,
+// byte-for-byte the geometry of an fp16 block-16 plane, so loader, ring and swizzle are shared.
+// HPO (their producers): besides the fp16 output, write those fp8 planes (p.T: lo8 p0, p1, hi8 p0, p1).
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R>;
+    static_assert(!F8 || R == 4, "the fp8 pair schedule is written for a 4-slot ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -261,7 +271,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 
     // One stage.  `do_issue` (workgroup-uniform): also issue the DMA of the stage R-1 ahead into
     // LDS slot `sl_off`, one instruction per B step, between the MFMAs.
-    auto stage_body = [&](const char* buf, bool do_issue, uint32_t sl_off, int r, bool capture) __attribute__((always_inline)) {
+    // n_issue (workgroup-uniform; 0/1, the F8 schedule also 2): stages whose DMA is issued from
+    // inside this stage, into LDS slots sl_off / sl_off1
+    constexpr int MAXI = F8 ? 2 : 1;
+    auto stage_body = [&](const char* buf, int n_issue, uint32_t sl_off, uint32_t sl_off1, int r, bool capture) __attribute__((always_inline)) {
         if (kTrunk && r < 4 && capture) {
 #pragma unroll
             for (int np = 0; np < NP; ++np) {
@@ -269,12 +282,15 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 hi_cap[r < 4 ? r : 0][np][1] = *(const u32x2*)(buf + (caddr[np] ^ 16));
             }
         }
-        const char* sb = nullptr;
-        const char* wb = nullptr;
-        if (do_issue) {
-            wb = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
-            sb = next_src();
-        }
+        const char* sbv[MAXI] = {nullptr};
+        const char* wbv[MAXI] = {nullptr};
+        const uint32_t slv[2] = {sl_off, sl_off1};
+#pragma unroll
+        for (int w = 0; w < MAXI; ++w)
+            if (w < n_issue) {
+                wbv[w] = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
+                sbv[w] = next_src();
+            }
         // A fragment of tap t = dy*3+dx is first needed at B step t (slab row s = dy), so the 9 taps
         // are fetched one step ahead of their first use instead of all up front: no LDS-read
         // bubble behind the barrier.
@@ -299,23 +315,25 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             // ... and stay there: without this fence hipcc sinks the reads back next to their use
             // (lgkmcnt(0/1) before every MFMA), which exposes the LDS latency on every step
             __builtin_amdgcn_sched_barrier(0);
-            if (do_issue) {
+            if (n_issue > 0)
 #pragma unroll
-                for (int sl = 0; sl < G::PW; ++sl) {
+            for (int sq = 0; sq < MAXI * G::PW; ++sq) {
+                constexpr int LASTSTEP = G::NBSTEP - 1;
 #if S2SR_DMA_LATE
-                    if ((G::NBSTEP - 1 - sl > 0 ? G::NBSTEP - 1 - sl : 0) != step) continue;   // DMA rides on the LAST steps
+                if ((LASTSTEP - sq > 0 ? LASTSTEP - sq : 0) != step) continue;   // DMA rides on the LAST steps
 #else
-                    if ((sl < G::NBSTEP - 1 ? sl : G::NBSTEP - 1) != step) continue;
+                if ((sq < LASTSTEP ? sq : LASTSTEP) != step) continue;
 #endif
-                    int j = wave + sl * WAVES;
-                    if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
-                    const uint32_t dst = lds0 + sl_off + (uint32_t)j * 1024;
-                    uint32_t vo = loff[sl];
-                    const char* bp = j < G::PI ? sb : wb;
-                    if (TRACE && (((p.dbg & 1) && j >= G::PI) || ((p.dbg & 2) && j < G::PI))) { vo = lane * 16; bp = (const char*)p.wpack; }
-                    if (TRACE && (p.dbg & 8)) continue;   // ablation: no DMA instruction at all
-                    glds16<(TRACE || EPI == EPI_DEBUG)>(bp, vo, dst);
-                }
+                const int w = sq / G::PW, sl = sq % G::PW;
+                if (w >= n_issue) continue;
+                int j = wave + sl * WAVES;
+                if (j > G::NSTI - 1) j = G::NSTI - 1;   // padding slot: same piece again
+                const uint32_t dst = lds0 + slv[w] + (uint32_t)j * 1024;
+                uint32_t vo = loff[sl];
+                const char* bp = j < G::PI ? sbv[w] : wbv[w];
+                if (TRACE && (((p.dbg & 1) && j >= G::PI) || ((p.dbg & 2) && j < G::PI))) { vo = lane * 16; bp = (const char*)p.wpack; }
+                if (TRACE && (p.dbg & 8)) continue;   // ablation: no DMA instruction at all
+                glds16<(TRACE || EPI == EPI_DEBUG)>(bp, vo, dst);
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -325,6 +343,120 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 for (int ct = 0; ct < CT; ++ct)
                     acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy * 3 + dx][ct], b[step % (D + 1)], acc[ct][np], 0, 0, 0);
             }
+        }
+    };
+
+    // ---- F8 kernels: both stage kinds walk dx -> slab row -> dy, so only the three A fragments of one
+    // kernel column are live (the 9-tap residency of stage_body plus the fp8 operands would spill).
+    // Every B fragment is still read once and feeds the kernel rows it belongs to.
+    constexpr int NB = NP + 2;
+    const char* sbv[2] = {nullptr, nullptr};
+    const char* wbv[2] = {nullptr, nullptr};
+    uint32_t slv[2] = {0, 0};
+    auto plan_dma = [&](int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
+        slv[0] = sl_off; slv[1] = sl_off1;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+            if (w < n_issue) {
+                wbv[w] = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
+                sbv[w] = next_src();
+            }
+    };
+    auto dma_step = [&](int step, int n_issue) __attribute__((always_inline)) {   // `step` is a compile-time constant at every call
+#pragma unroll
+        for (int sq = 0; sq < 2 * G::PW; ++sq) {
+            constexpr int LASTSTEP = 3 * NB - 1;
+            if ((sq < LASTSTEP ? sq : LASTSTEP) != step) continue;
+            const int w = sq / G::PW, sl = sq % G::PW;
+            if (w >= n_issue) continue;
+            int j = wave + sl * WAVES;
+            if (j > G::NSTI - 1) j = G::NSTI - 1;
+            glds16<(TRACE || EPI == EPI_DEBUG)>(j < G::PI ? sbv[w] : wbv[w], loff[sl], lds0 + slv[w] + (uint32_t)j * 1024);
+        }
+    };
+    // hipcc sinks the (side-effect free) MFMAs of a finished column below the next wait/barrier and keeps
+    // every fragment they read alive across it; passing the accumulators through an empty volatile asm
+    // pins the column's MFMAs where they were written
+    auto pin_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int np = 0; np < NP; ++np) asm volatile("" : "+v"(acc[ct][np]));
+    };
+    auto stage16_dx = [&](const char* buf, int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
+        plan_dma(n_issue, sl_off, sl_off1);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            __builtin_amdgcn_sched_barrier(0);
+            f16x8 a[3][CT];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) a[dy][ct] = *(const f16x8*)(buf + aaddr + ((dy * 3 + dx) * CT + ct) * 1024);
+            f16x8 b[2];
+            b[0] = *(const f16x8*)(buf + baddr[0][dx]);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                if (s + 1 < NB) b[(s + 1) & 1] = *(const f16x8*)(buf + baddr[s + 1][dx]);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_step(dx * NB + s, n_issue);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int np = s - dy;
+                    if (np < 0 || np >= NP) continue;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy][ct], b[s & 1], acc[ct][np], 0, 0, 0);
+                }
+            }
+            pin_acc();
+        }
+    };
+    // Two fp8 planes (ring slots at LDS offsets offA / offB) as one K=64 step per tap: lanes 0-31
+    // take their 32 K bytes from the first plane, lanes 32-63 from the second.  The two 16-B halves
+    // of a pixel are read in physical order (one address + immediate) and put into channel order
+    // with v_cndmask on the loader's swizzle bit.
+    auto pair_body = [&](uint32_t offA, uint32_t offB, int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
+        plan_dma(n_issue, sl_off, sl_off1);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const char* mb = smem + (hh ? offB : offA);
+        const uint32_t afrag = G::PLANE + pcol * 16;
+        auto bfrag = [&](int s, int dx) __attribute__((always_inline)) -> v8i {
+            const uint32_t pa = baddr[s][dx] & ~16u;                 // physical half 0 of the pixel
+            const v4i x0 = *(const v4i*)(mb + pa), x1 = *(const v4i*)(mb + pa + 16);
+            const bool sw = (pa >> 8) & 1;                           // bit 3 of the pixel index: halves stored swapped
+            const v4i l0 = sw ? x1 : x0, l1 = sw ? x0 : x1;
+            return __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            __builtin_amdgcn_sched_barrier(0);
+            v8i a8[3][CT];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const char* fp = mb + afrag + (uint32_t)((dy * 3 + dx) * CT + ct) * 1024;
+                    const v4i x0 = *(const v4i*)(fp), x1 = *(const v4i*)(fp + 512);
+                    a8[dy][ct] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            v8i b8[2];
+            b8[0] = bfrag(0, dx);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                if (s + 1 < NB) b8[(s + 1) & 1] = bfrag(s + 1, dx);
+                __builtin_amdgcn_sched_barrier(0);
+                dma_step(dx * NB + s, n_issue);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int np = s - dy;
+                    if (np < 0 || np >= NP) continue;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)   // e4m3 x e4m3, scale_a = 2^0, scale_b = 2^-11 (E8M0 bytes 127, 116)
+                        acc[ct][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[dy][ct], b8[s & 1], acc[ct][np], 0, 0, 0, 127, 0, 116);
+                }
+            }
+            pin_acc();
         }
     };
 
@@ -388,6 +520,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             for (int ct = 0; ct < CT; ++ct) {
                 u32x2 hpk[4];   // fp16 x4 per g (hi / plain output)
                 u32x2 lpk[4];   // fp16 x4 per g (lo), trunk forms and conv_first
+                uint32_t lo8[4], hi8[4];   // e4m3 x4 per g (HPO): channels 8g+4hh .. +3 of fp8 plane ct
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cb = ct * 32 + 8 * g + 4 * hh;   // first of this lane's 4 consecutive couts
@@ -438,11 +571,26 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 #pragma unroll
                         for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
                         hpk[g] = __builtin_bit_cast(u32x2, hv);
-                        if (kTrunk || EPI == EPI_FIRST || HPO) {
+                        if (kTrunk || EPI == EPI_FIRST) {
                             f16x4 lv;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) lv[i] = (f16)__fsub_rn(v[i], (float)hv[i]);
                             lpk[g] = __builtin_bit_cast(u32x2, lv);
+                        } else if (HPO) {
+                            // e4m3 copies for the consumer's correction terms: lo*2^11 and hi, clamped to the
+                            // finite range (v_cvt_pk_fp8_f32 turns anything past 448 into NaN)
+                            float l4[4], h4[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                l4[i] = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[i], (float)hv[i]), 2048.0f), -448.0f, 448.0f);
+                                h4[i] = __builtin_amdgcn_fmed3f((float)hv[i], -448.0f, 448.0f);
+                            }
+                            int lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
+                            lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], lw, true);
+                            int hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[0], h4[1], 0, false);
+                            hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[2], h4[3], hw, true);
+                            lo8[g] = (uint32_t)lw;
+                            hi8[g] = (uint32_t)hw;
                         }
                     }
                 }
@@ -458,13 +606,26 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         u32x4 o;
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                         *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
-                        if (kTrunk || EPI == EPI_FIRST || HPO) {
+                        if (kTrunk || EPI == EPI_FIRST) {
                             u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
                             const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
                             const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
                             u32x4 ol;
                             ol[0] = q0[0]; ol[1] = q1[0]; ol[2] = q0[1]; ol[3] = q1[1];
                             *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = ol;
+                        }
+                    }
+                    if (HPO && !kTrunk && EPI != EPI_FIRST) {
+                        // the lane holds dwords 2g+hh of the pixel's 32 plane bytes; after the swaps
+                        // lanes 0-31 hold dwords 0-3, lanes 32-63 dwords 4-7: one 16-B store each
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const uint32_t* d = w ? hi8 : lo8;
+                            const auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+                            const auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+                            u32x4 o;
+                            o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
+                            *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(2 * w + ct) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
                         }
                     }
                 }
@@ -497,6 +658,59 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     bool after_epi = false;
     constexpr int NST = EpiStores<EPI, CT, NP, HPO>::value;
     constexpr int NW = G::PW * (R - 2);
+    if constexpr (F8) {
+        // Patch = ring revolution A (4 fp16 stages, slots 0..3) + revolution B (fp8 pairs in slots
+        // (0,1) and (2,3)).  A pair frees two slots at once, so the issue cursor runs 1-2-1-1 /
+        // 1-2 stages per turn instead of one; `issued` counts stages whose DMA is out, the wait
+        // before a turn allows exactly the stages issued after the one it needs.
+        constexpr int PWn = G::PW;
+        int issued = S < R - 1 ? S : R - 1;
+        auto wait_pending = [&](int pend) __attribute__((always_inline)) {
+            const bool epi = after_epi && NST > 0;
+            if (pend >= 2) {
+                if (epi) wait_vm_barrier<(NST > 0 ? 2 * PWn + NST : 2 * PWn)>();
+                else wait_vm_barrier<2 * PWn>();
+            } else if (pend == 1) {
+                if (epi) wait_vm_barrier<(NST > 0 ? PWn + NST : PWn)>();
+                else wait_vm_barrier<PWn>();
+            } else {
+                wait_vm_barrier<0>();
+            }
+            after_epi = false;
+        };
+        static_assert(2 * PWn + (NST > 0 ? NST : 0) < 64, "vmcnt field is 6 bits");
+        uint32_t sl0 = 0, sl1 = 0;
+        auto plan_issue = [&](int upto) __attribute__((always_inline)) -> int {   // issue every stage up to `upto` (slot known free)
+            const int t = upto < S - 1 ? upto : S - 1;
+            int n = t - (issued - 1);
+            n = n < 0 ? 0 : n;
+            sl0 = (uint32_t)((issued & 3) * G::STAGE_BYTES);
+            sl1 = (uint32_t)(((issued + 1) & 3) * G::STAGE_BYTES);
+            issued += n;
+            return n;
+        };
+        while (k < S) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wait_pending(issued - 1 - k);
+                const int n = plan_issue(k + 3);
+                stage16_dx(smem + r * G::STAGE_BYTES, n, sl0, sl1);
+                ++k;
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                wait_pending(issued - 1 - (k + 1));
+                const int n = plan_issue(k + 3);
+                pair_body((uint32_t)((2 * pr) * G::STAGE_BYTES), (uint32_t)((2 * pr + 1) * G::STAGE_BYTES), n, sl0, sl1);
+                k += 2;
+            }
+            epilogue(it_c);
+            init_acc();
+            ++it_c;
+            after_epi = true;
+        }
+        return;
+    }
     // one ring revolution per loop trip; every condition below is workgroup-uniform
     while (k < S) {
 #pragma unroll
@@ -512,7 +726,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 }
                 after_epi = false;
                 S2SR_STAMP(2 + 2 * k);
-                stage_body(smem + r * G::STAGE_BYTES, k + (R - 1) < S, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), r,
+                stage_body(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u, r,
                            st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
                 S2SR_STAMP(3 + 2 * k);
                 if (++st_c == NS) {
@@ -540,12 +754,13 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1>
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R>;
     static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
-    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC>;
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8>;
+    if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
     static bool attr_set = false;
     static int ncu = 256;
     if (!attr_set) {
@@ -586,13 +801,16 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }
 
-hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_out, hipStream_t st) {
-    if (lo_out) {   // 64-channel outputs that also write their lo half (split-operand mode)
-        if (ct != 2) return hipErrorInvalidValue;
-        if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, true>(p, st);
-        if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, true>(p, st);
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_out, hipStream_t st, bool f8_in) {
+    if (f8_in) {   // split-operand mode: fp16 main term + fp8 correction planes in; lo_out: fp8 planes out as well
+        if (ct == 2 && lo_out) {
+            if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, true, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, true, 1, true>(p, st);
+            if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, true, 1, true>(p, st);
+        }
+        if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 8, 2, 4, false, false, 1, true>(p, st);
         return hipErrorInvalidValue;
     }
+    if (lo_out) return hipErrorInvalidValue;
     if (ct == 1) {
         if (epi == EPI_LRELU && !up) return launch_w<1, EPI_LRELU, false>(p, st);
         if (epi == EPI_LAST && !up) return launch_w<1, EPI_LAST, false>(p, st);
@@ -662,6 +880,47 @@ void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_ho
                             *d++ = lo ? (f16)(v - (float)hi) : hi;
                         }
     }
+}
+
+uint8_t f32_to_e4m3(float f) {
+    if (f != f) return 0x7f;
+    const uint8_t sign = (f < 0.f || (f == 0.f && 1.f / f < 0.f)) ? 0x80 : 0;
+    const float a = fabsf(f);
+    if (a >= 464.f) return sign | 0x7e;          // past the midpoint to the NaN code: saturate at 448
+    if (a == 0.f) return sign;
+    int e;
+    (void)frexpf(a, &e);                         // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;
+    if (E < -6) {                                // subnormal: steps of 2^-9
+        int q = (int)rintf(a * 512.f);           // ties to even (default rounding mode)
+        return sign | (uint8_t)(q >= 8 ? 0x08 : q);
+    }
+    int q = (int)rintf(ldexpf(a, 3 - E));        // 8 .. 16
+    if (q == 16) { q = 8; ++E; }
+    if (E > 8 || (E == 8 && q > 14)) return sign | 0x7e;
+    return sign | (uint8_t)(((E + 7) << 3) | (q - 8));
+}
+
+void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host) {
+    const int CT = (cout + 31) / 32;
+    pack_conv_weights(w, cin, cout, 1, dst_host);                       // stages 0..3: fp16 w_hi
+    uint8_t* d = (uint8_t*)dst_host + conv_wpack_bytes_seg(cin, cout, 1);
+    for (int part = 0; part < 2; ++part)                                // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
+        for (int pl = 0; pl < 2; ++pl)
+            for (int t = 0; t < 9; ++t)
+                for (int ct = 0; ct < CT; ++ct)
+                    for (int h16 = 0; h16 < 2; ++h16)
+                        for (int row = 0; row < 32; ++row)
+                            for (int j = 0; j < 16; ++j) {
+                                const int co = ct * 32 + row, ci = 32 * pl + 16 * h16 + j;
+                                float v = 0.f;
+                                if (co < cout && ci < cin) {
+                                    const float x = w[((size_t)co * cin + ci) * 9 + t];
+                                    const float hi = (float)(f16)x;
+                                    v = part == 0 ? hi : (x - hi) * 2048.0f;
+                                }
+                                *d++ = f32_to_e4m3(v);
+                            }
 }
 
 }  // namespace s2sr

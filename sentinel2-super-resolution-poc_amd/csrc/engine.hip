@@ -23,6 +23,7 @@ struct ConvW {
     int cin = 0, cout = 0, nstage = 0, ct = 0;
     int seg_len = 0, seg_lo_mask = 0;   // split-operand convs (precision S2SR_PREC_F16_HP), see ConvParams
     bool fold = false;                  // conv_last in hp mode: w_lo folded into idle couts (pack_conv_weights)
+    bool f8 = false;                    // hp mode, cin 64: fp16 main term + e4m3 correction planes (pack_conv_weights_f8hp)
     void* d_wpack = nullptr;
     float* d_bias = nullptr;
 };
@@ -44,8 +45,9 @@ struct Workspace {
     float *R = nullptr, *F = nullptr;    // fp32 RRDB skip / global skip (8 blocks of 8)
     // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
-    // lo halves of U0..U3 (split-operand mode only)
-    char *U0lo = nullptr, *U1lo = nullptr, *U2lo = nullptr, *U3lo = nullptr;
+    // split-operand mode only: e4m3 correction planes of U0..U3 and of the trunk, 4 planes of 32 B per
+    // pixel each ([lo*2^11 p0, p1, hi p0, p1]) -- the size of a 4-block fp16 tensor
+    char *U0lo = nullptr, *U1lo = nullptr, *U2lo = nullptr, *U3lo = nullptr, *T8 = nullptr;
     bool hp = false;
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
     size_t blk1 = 0, blk2 = 0, blk4 = 0;   // bytes of one block plane at 1x / 2x / 4x
@@ -181,7 +183,11 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
     size_t oU0l = 0, oU1l = 0, oU2l = 0, oU3l = 0;
-    if (hp) { oU0l = take(g * 4 * w.blk1); oU1l = take(g * 4 * w.blk2); oU2l = take(g * 4 * w.blk4); oU3l = take(g * 4 * w.blk4); }
+    size_t oT8 = 0;
+    if (hp) {
+        oU0l = take(g * 4 * w.blk1); oU1l = take(g * 4 * w.blk2); oU2l = take(g * 4 * w.blk4); oU3l = take(g * 4 * w.blk4);
+        oT8 = take(g * 4 * w.blk1);
+    }
     w.bytes = off;
     HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
@@ -189,7 +195,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.U0 = w.base + oU0;
     w.T = w.base + oT; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
-    if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; }
+    if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; w.T8 = w.base + oT8; }
     return S2SR_OK;
 }
 
@@ -259,7 +265,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
-    HIPCHK(h, launch_conv(p, cw.ct, epi, up, lo_out, st));
+    HIPCHK(h, launch_conv(p, cw.ct, epi, up, lo_out, st, cw.f8));
     return S2SR_OK;
 }
 
@@ -299,7 +305,11 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
     {   // conv_body + global skip; its input is the trunk: hi = x (dense blocks 0..3), lo = trunk lo
         ConvParams p = b;
         p.src = w.D[cur]; p.src_img = 12 * w.blk1; p.dst = w.U0; p.dst_img = 4 * w.blk1;
-        if (hp) { p.src_lo = w.T; p.lo_img = 4 * w.blk1; p.T = w.U0lo; }
+        if (hp) {
+            Scope sc(h, st, F_MISC, 0.0, (double)n * w.Hp * w.Wp * (256.0 + 128.0));
+            HIPCHK(h, launch_trunk_to_fp8(w.D[cur], 12 * w.blk1, w.T, 4 * w.blk1, n, w.Hp, w.Wp, w.T8, st));
+            p.src_lo = w.T8; p.lo_img = 4 * w.blk1; p.T = w.U0lo;
+        }
         if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false, hp))) return rc;
     }
     {   // conv_up1 on nearest-2x
@@ -537,13 +547,18 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         const bool split = hp && (idx == 0 || idx + 5 >= nconv);
         // conv_first's inputs are exact integers: no x_lo.  conv_last has 29 idle output channels: w_lo
         // rides in couts 8..10 of both segments (x_hi, x_lo), one pass over x_hi less
-        const bool fold = split && idx + 1 == nconv && s.cout <= 8;
-        const int nseg = !split ? 1 : ((idx == 0 || fold) ? 2 : 3);
+        // All the others (cin 64): x_hi*w_hi on the fp16 MFMA, x_lo*w_hi + x_hi*w_lo as e4m3 planes on the
+        // block-scaled fp8 MFMA (twice the rate, half the bytes; 2^-15-relative error on 2^-11-sized terms).
+        const bool f8 = split && idx != 0 && s.cin == 64;
+        const bool fold = split && !f8 && idx + 1 == nconv && s.cout <= 8;
+        const int nseg = !split ? 1 : ((idx == 0 || fold || f8) ? 2 : 3);
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
-        cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold) ? 0x2 : 0x0;
+        cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold || f8) ? 0x2 : 0x0;
+        cw.f8 = f8;
         const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
         tmp.resize(wb);
-        pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
+        if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
+        else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
         cw.fold = fold;
         pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));

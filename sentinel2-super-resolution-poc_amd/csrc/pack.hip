@@ -61,6 +61,48 @@ hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, fl
     return hipGetLastError();
 }
 
+// conv_body's correction operands (S2SR_PREC_F16_HP): the trunk arrives as an fp16 pair (hi = dense
+// blocks 0..3, lo = the trunk-lo tensor); the split-operand kernel wants e4m3 planes of 32 channels
+// [lo*2^11 plane 0, plane 1, hi plane 0, plane 1] in the same padded geometry (halo pixels are zero
+// in both inputs, so the whole padded tensor is converted).  One thread = one pixel of one plane.
+__global__ void trunk_to_fp8_kernel(const char* __restrict__ hi, size_t hi_img, const char* __restrict__ lo, size_t lo_img,
+                                    int N, size_t ppx, char* __restrict__ out) {
+    const size_t total = (size_t)N * 4 * ppx;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % ppx;
+        const int plane = (int)((i / ppx) & 3);
+        const int n = (int)(i / (4 * ppx));
+        const bool is_hi = plane >= 2;
+        const char* src = (is_hi ? hi + (size_t)n * hi_img : lo + (size_t)n * lo_img) + (size_t)(2 * (plane & 1)) * ppx * 32 + pix * 32;
+        const float scale = is_hi ? 1.0f : 2048.0f;
+        uint32_t o[8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {   // two fp16 blocks of 16 channels -> 32 e4m3 bytes
+            const f16* v = (const f16*)(src + (size_t)b * ppx * 32);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = __builtin_amdgcn_fmed3f((float)v[4 * q + k] * scale, -448.0f, 448.0f);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+                o[4 * b + q] = (uint32_t)w;
+            }
+        }
+        uint4* d = (uint4*)(out + ((size_t)n * 4 + plane) * ppx * 32 + pix * 32);
+        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int N, int Hp, int Wp, char* out,
+                               hipStream_t st) {
+    const size_t ppx = (size_t)Hp * Wp, total = (size_t)N * 4 * ppx;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(trunk_to_fp8_kernel, dim3(grid), dim3(256), 0, st, hi, hi_img, lo, lo_img, N, ppx, out);
+    return hipGetLastError();
+}
+
 __global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
                                       int T, int wh, int ww, uint8_t* __restrict__ tiles) {
     const size_t total = (size_t)T * wh * ww * 3;

@@ -75,7 +75,7 @@ struct ConvParams {
 };
 
 // conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.
-hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool lo_out, hipStream_t st);
+hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool lo_out, hipStream_t st, bool f8_in = false);
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
@@ -84,11 +84,18 @@ size_t conv_wpack_bytes(int cin, int cout);
 // output channels gets x*w_hi and x*w_lo from one pass over x (conv_last in hp mode: 2 segments, x_hi and x_lo)
 void pack_conv_weights(const float* w, int cin, int cout, int nseg, void* dst_host, bool fold = false);
 size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
+// split-operand convs with fp8 correction terms (cin == 64): 4 fp16 stages [w_hi] + 4 e4m3 stages
+// [w_hi ch 0-31][w_hi ch 32-63][w_lo*2^11 ch 0-31][w_lo*2^11 ch 32-63]; an fp8 stage fragment is
+// [tap][ct][16-B half][cout row 0..31][16 channel bytes].  Same size as nseg = 2.
+void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host);
+uint8_t f32_to_e4m3(float f);   // OCP e4m3fn, round to nearest even, saturating at +-448
 
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);
 hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB,
                                 int Hp, int Wp, hipStream_t st);
+hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int N, int Hp, int Wp, char* out,
+                               hipStream_t st);
 hipError_t launch_gather_windows(const uint8_t* d_img, int H, int W, const int32_t* d_rects, int T, int wh, int ww,
                                  uint8_t* d_tiles, hipStream_t st);
 hipError_t launch_stitch_u8(const uint8_t* d_tiles, int tilesX, int oth, int otw, const int32_t* d_rowmap,
