@@ -385,19 +385,22 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     };
     auto stage16_dx = [&](const char* buf, int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
         plan_dma(n_issue, sl_off, sl_off1);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            __builtin_amdgcn_sched_barrier(0);
-            f16x8 a[3][CT];
+        f16x8 a[2][3][CT];   // this column's fragments and the next column's, fetched a column ahead
+        auto load_a = [&](int dx) __attribute__((always_inline)) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) a[dy][ct] = *(const f16x8*)(buf + aaddr + ((dy * 3 + dx) * CT + ct) * 1024);
+                for (int ct = 0; ct < CT; ++ct) a[dx & 1][dy][ct] = *(const f16x8*)(buf + aaddr + ((dy * 3 + dx) * CT + ct) * 1024);
+        };
+        load_a(0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
             f16x8 b[2];
             b[0] = *(const f16x8*)(buf + baddr[0][dx]);
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 if (s + 1 < NB) b[(s + 1) & 1] = *(const f16x8*)(buf + baddr[s + 1][dx]);
+                if (s == 0 && dx < 2) load_a(dx + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 dma_step(dx * NB + s, n_issue);
 #pragma unroll
@@ -406,7 +409,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                     if (np < 0 || np >= NP) continue;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy][ct], b[s & 1], acc[ct][np], 0, 0, 0);
+                        acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dx & 1][dy][ct], b[s & 1], acc[ct][np], 0, 0, 0);
                 }
             }
             pin_acc();
@@ -428,23 +431,26 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             const v4i l0 = sw ? x1 : x0, l1 = sw ? x0 : x1;
             return __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            __builtin_amdgcn_sched_barrier(0);
-            v8i a8[3][CT];
+        v8i a8[2][3][CT];
+        auto load_a8 = [&](int dx) __attribute__((always_inline)) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const char* fp = mb + afrag + (uint32_t)((dy * 3 + dx) * CT + ct) * 1024;
                     const v4i x0 = *(const v4i*)(fp), x1 = *(const v4i*)(fp + 512);
-                    a8[dy][ct] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    a8[dx & 1][dy][ct] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+        };
+        load_a8(0);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
             v8i b8[2];
             b8[0] = bfrag(0, dx);
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 if (s + 1 < NB) b8[(s + 1) & 1] = bfrag(s + 1, dx);
+                if (s == 1 && dx < 2) load_a8(dx + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 dma_step(dx * NB + s, n_issue);
 #pragma unroll
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                     if (np < 0 || np >= NP) continue;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)   // e4m3 x e4m3, scale_a = 2^0, scale_b = 2^-11 (E8M0 bytes 127, 116)
-                        acc[ct][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[dy][ct], b8[s & 1], acc[ct][np], 0, 0, 0, 127, 0, 116);
+                        acc[ct][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[dx & 1][dy][ct], b8[s & 1], acc[ct][np], 0, 0, 0, 127, 0, 116);
                 }
             }
             pin_acc();
