@@ -184,7 +184,7 @@ def main():
                        "net_TFLOP_per_s_per_gpu": round(tiles_per_s / world * TILE * TILE * FLOP_PER_LR_PX / 1e12, 1),
                        "group": a.group, "weights": "seeded synthetic RealESRGAN_x4plus shapes (seed 0)",
                        "precision": ("fp16 MFMA operands, fp32 accumulate, trunk as fp16 hi/lo pair; the 6 convs outside the "
-                                     "RRDB trunk with split operands: max-abs 2e-5..9e-5 vs the fp32 reference"
+                                     "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 7e-5..1.2e-4 vs the fp32 reference"
                                      if a.precision == "hp" else
                                      "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1),

@@ -44,10 +44,13 @@ struct ConvParams {
     const char* src;         // first input block of image 0 (fp16 blocked tensor)
     uint64_t src_img;        // bytes between images of src
     int32_t nstage;          // pipeline stages per patch = nseg * seg_len
-    // Split-operand ("hp") convs run the K loop over up to three segments of seg_len blocks that all
-    // accumulate into the same fp32 accumulator: (x_hi,w_hi) (x_lo,w_hi) (x_hi,w_lo).  Bit s of
-    // seg_lo_mask says segment s reads the lo tensor.  Plain convs: seg_len == nstage, mask 0.
-    const char* src_lo;      // lo part of the input (fp16 blocked, same geometry as src), or null
+    // Split-operand ("hp") convs run the K loop over segments of seg_len stages that all accumulate
+    // into the same fp32 accumulator.  Bit s of seg_lo_mask says segment s reads the src_lo tensor.
+    //   conv_first: (x, w_hi) (x, w_lo), both fp16 (x is an exact integer);
+    //   cin-64 convs (f8_in launch): 4 fp16 stages (x_hi, w_hi), then the 4 e4m3 planes of src_lo
+    //   [x_lo*2^11 p0, p1, x_hi p0, p1] against [w_hi, w_hi, w_lo*2^11, w_lo*2^11] on the fp8 MFMA.
+    // Plain convs: seg_len == nstage, mask 0.
+    const char* src_lo;      // second operand tensor (same padded geometry as src: fp16 lo blocks or e4m3 planes), or null
     uint64_t lo_img;         // bytes between images of src_lo
     int32_t seg_len;
     int32_t seg_lo_mask;
@@ -60,7 +63,7 @@ struct ConvParams {
     char* dst;               // first OUTPUT block of image 0 (fp16 blocked tensor)
     uint64_t dst_img;        // bytes between images of dst
     char* T;                 // 'lo' OUTPUT tensor: fp16 blocked-16, 4 blocks, image stride 4 blocks.  conv_first / conv5:
-                             // the trunk lo (trunk = x + lo); hp convs: lo of their 64-channel output
+                             // the trunk lo (trunk = x + lo); hp convs: the 4 e4m3 planes of their 64-channel output
     float* R; float* F;      // fp32 blocked-8 skip tensors (RRDB input, global skip), 8 blocks
     float* out_f32;          // EPI_LAST / EPI_DEBUG: [N,cout,H,W] fp32 (may be null)
     uint8_t* out_u8;         // EPI_LAST: [N,H,W,3] u8 (may be null)
