@@ -755,11 +755,6 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R>;
@@ -795,14 +790,11 @@ template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     constexpr int R = (CT == 1) ? 5 : 4;
     if (CT == 1 && EPI == EPI_LRELU && !UP) {
-        static const int waves = env_int("S2SR_CT1_WAVES", 84);
-        if (waves == 4) return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
-        // 32x32 patch, 3-deep ring -- unless that leaves most CUs without a patch (single tiles):
-        // then the 16x32 patch spreads the image over twice as many workgroups
+        // the 32-cout RDB convs: 32x32 patch (4 rows per wave), 3-deep ring -- unless that leaves most
+        // CUs without a patch (single tiles): then the 16x32 patch spreads the image over twice as
+        // many workgroups
         const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
-        if (waves == 84 && n32 >= 192) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);
-        if (waves == 82) return launch_t<1, EPI_LRELU, false, 8, 2, 2, false, false, 2>(p, st);   // 2 WGs per CU, double buffer
-        if (waves == 83) return launch_t<1, EPI_LRELU, false, 8, 2, 3, false, false, 1>(p, st);
+        if (n32 >= 192) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);
     }
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
 }
