@@ -155,6 +155,10 @@ int  s2sr_synchronize(s2sr_handle* h);
  * stream and profiling runs use direct launches).  Counters since s2sr_create. */
 int  s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays);
 
+/* test hook (host only, no GPU): the OCP e4m3fn encoder the weight packer uses for the fp8
+ * correction stages -- round to nearest even, saturating at +-448, NaN -> 0x7f. */
+uint8_t s2sr_debug_f32_to_e4m3(float v);
+
 /* test hook: one 3x3 conv layer on NCHW fp32 host tensors through the production kernel
  * (upsample != 0 -> nearest-2x on load).  act: 0 none, 1 LeakyReLU(0.2). */
 int  s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W,

@@ -893,6 +893,8 @@ int s2sr_synchronize(s2sr_handle* h) {
     return S2SR_OK;
 }
 
+uint8_t s2sr_debug_f32_to_e4m3(float v) { return f32_to_e4m3(v); }
+
 int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W, const float* weight,
                     const float* bias, int32_t Cout, int32_t upsample, int32_t act, float* y) {
     if (!h || !x || !weight || !bias || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 64 || H <= 0 || W <= 0)

@@ -81,6 +81,7 @@ _PROTOS = {
     "s2sr_get_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KStat), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
+    "s2sr_debug_f32_to_e4m3": (C.c_uint8, [C.c_float]),
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),

@@ -61,3 +61,24 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("a GPU is visible")
     with pytest.raises(native.S2srError):
         native.Engine(num_block=1)
+
+
+def test_e4m3_encoder_matches_torch():
+    """The weight packer's fp8 encoder (OCP e4m3fn, RNE, saturating) against torch's float8_e4m3fn
+    on a sweep that covers subnormals, ties and every binade up to the finite maximum."""
+    import torch
+
+    lib = native.load_library()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        np.array([0.0, -0.0, 2.0 ** -10, 2.0 ** -9, 1.5 * 2.0 ** -9, 2.0 ** -6, 1.0625, 1.1875, 447.9, 448.0], np.float32),
+        (rng.standard_normal(4000) * np.exp2(rng.integers(-12, 9, 4000))).astype(np.float32),
+        np.ldexp(np.arange(8, 17, dtype=np.float32) + 0.5, -3),           # exact ties between neighbours
+    ])
+    vals = vals[np.abs(vals) <= 448.0]
+    want = torch.from_numpy(vals).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = np.array([lib.s2sr_debug_f32_to_e4m3(float(v)) for v in vals], np.uint8)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(float(vals[i]), hex(got[i]), hex(want[i])) for i in bad[:5]]
+    assert lib.s2sr_debug_f32_to_e4m3(1e9) == 0x7E and lib.s2sr_debug_f32_to_e4m3(-1e9) == 0xFE   # saturate, never NaN
+    assert lib.s2sr_debug_f32_to_e4m3(float("nan")) == 0x7F

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""AOI mosaic path (BASELINE configs[2] on one GPU): s2sr_enhance_u8 on host images, window plans
+256/10 (the reference default) and 512/10."""
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+import numpy as np  # noqa: E402
+
+from s2sr import native  # noqa: E402
+from s2sr.weights import synthetic_state_dict  # noqa: E402
+
+e = native.Engine(num_block=23, precision=native.PREC_F16_HP)
+e.load_state_dict(synthetic_state_dict(23, seed=0))
+rng = np.random.default_rng(4321)
+for side in (1024, 2048):
+    img = rng.integers(0, 256, (side, side, 3), dtype=np.uint8)
+    for tile in (256, 512):
+        nwin = len(native.plan_tiles(side, side, tile, 10))
+        e.enhance_u8(img, tile=tile, pad=10)
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            out = e.enhance_u8(img, tile=tile, pad=10)
+        dt = (time.perf_counter() - t0) / n
+        print(f"{side}x{side} tile {tile}: {nwin} windows, {dt*1e3:.1f} ms, {16*side*side/1e6/dt:.1f} SR-MP/s "
+              f"(host in/out, {16*side*side*3/1e6:.0f} MB out)", flush=True)
