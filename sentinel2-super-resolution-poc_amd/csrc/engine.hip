@@ -742,6 +742,51 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, launch_gather_windows((const uint8_t*)h->d_scratch[0], H, W, d_rects, T, wh, ww, (uint8_t*)h->d_scratch[2], st));
+        const int G = group_size(h, T, wh, ww);
+        if (!out_f32 && T > G) {
+            // Big mosaics: whole window rows in chunks of >= G windows.  An output row is final once the
+            // last window row that pastes into it is done (the row map is monotone), so each chunk is
+            // followed by the stitch of its band of final rows, and the band's device-to-host copy runs
+            // on the copy stream under the next chunk's compute.
+            const int rpc = (G + nx - 1) / nx;
+            const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
+            const int nchunks = (ny + rpc - 1) / rpc;
+            while ((int)h->group_done.size() < nchunks) {
+                hipEvent_t e;
+                HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->group_done.push_back(e);
+            }
+            uint8_t* d_img_out = (uint8_t*)h->d_scratch[1];
+            int yb = 0, prev_yb = 0, prev_ye = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                const int r0 = c * rpc, r1 = (r0 + rpc < ny) ? r0 + rpc : ny;
+                const int t0 = r0 * nx, n = (r1 - r0) * nx;
+                rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[2] + t0 * win_in, nullptr, n, wh, ww,
+                                 (uint8_t*)h->d_scratch[4] + t0 * win_out, nullptr);
+                if (rc) return rc;
+                int ye = OH;
+                if (r1 < ny)
+                    for (ye = yb; ye < OH && rm[2 * ye] < r1; ++ye) {}
+                if (ye > yb)
+                    HIPCHK(h, launch_stitch_u8((const uint8_t*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm + 2 * yb, d_cm, ye - yb, OW,
+                                               d_img_out + (size_t)yb * OW * 3, st));
+                HIPCHK(h, hipEventRecord(h->group_done[c], st));
+                if (c > 0 && prev_ye > prev_yb) {
+                    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[c - 1], 0));
+                    HIPCHK(h, hipMemcpyAsync(out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
+                                             (size_t)(prev_ye - prev_yb) * OW * 3, hipMemcpyDeviceToHost, h->copy_stream));
+                }
+                prev_yb = yb; prev_ye = ye; yb = ye;
+            }
+            if (prev_ye > prev_yb) {
+                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks - 1], 0));
+                HIPCHK(h, hipMemcpyAsync(out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
+                                         (size_t)(prev_ye - prev_yb) * OW * 3, hipMemcpyDeviceToHost, h->copy_stream));
+            }
+            HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+            HIPCHK(h, hipStreamSynchronize(st));
+            return S2SR_OK;
+        }
         rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[2], nullptr, T, wh, ww, out_f32 ? nullptr : (uint8_t*)h->d_scratch[4],
                          out_f32 ? (float*)h->d_scratch[4] : nullptr);
         if (rc) return rc;

@@ -295,3 +295,28 @@ def test_graph_replay_is_bit_identical(monkeypatch):
     assert np.array_equal(a, b) and np.array_equal(a, c)
     assert np.array_equal(e.forward_batch_u8(tiles), want)
     e.close()
+
+
+def test_banded_mosaic_path_matches_single_pass():
+    """More windows than one group: whole window rows are run in chunks, each followed by the stitch
+    and the overlapped copy of its band of final output rows.  Must equal the oracle's sequential
+    paste (u8, HP mode) and the float path, which still stitches once at the end."""
+    nb = 1
+    sd = synthetic_state_dict(nb, seed=0)
+    tsd = ref.to_torch_sd(sd)
+    e = engine(nb, native.PREC_F16_HP)
+    rng = np.random.default_rng(33)
+    for (H, W, ts, tp) in [(100, 90, 16, 2), (53, 200, 16, 3), (130, 37, 16, 2)]:
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        nwin = len(native.plan_tiles(H, W, ts, tp))
+        assert nwin > 16
+        q = e.enhance_u8(img, tile=ts, pad=tp)
+        f = e.enhance_f32(img, tile=ts, pad=tp)
+        exp_u8, exp_f = ref.enhance(img, tsd, nb, tile_size=ts, tile_pad=tp, return_float=True)
+        assert np.abs(f - exp_f).max() <= TOL_HP
+        d = np.abs(q.astype(np.int16) - exp_u8.astype(np.int16))
+        # the banded u8 result must be exactly the quantised float result of the same engine
+        qf = np.clip(f * np.float32(255.0), 0, 255).astype(np.uint8)
+        print(f"banded {H}x{W}: {nwin} windows, u8 vs oracle identical {np.mean(d == 0):.4f}, vs own float {np.mean(q == qf):.4f}")
+        assert d.max() <= 1 and np.mean(d == 0) >= 0.98
+        assert np.array_equal(q, qf)
