@@ -107,3 +107,37 @@ def test_http_wow_and_sr_jobs(monkeypatch, tmp_path):
     st3 = c.get(f"/api/sr/{r3.json()['job_id']}").json()
     assert st3["status"] == "failed" and "Unknown model" in st3["message"]
     assert len(tiled) == 2 and set(c.get("/api/sr").json()["jobs"]) >= {r.json()["job_id"]}
+
+
+def test_concurrent_jobs_share_one_engine(monkeypatch, tmp_path):
+    """The reference runs /api/wow and /api/sr jobs from Starlette worker threads with no gate
+    (main.py:66,602,670-675): several threads construct RealESRGAN and call enhance at once.  They
+    share the cached native engine, which serialises calls per handle; results must equal the
+    serial ones (different shapes force workspace / graph turnover between calls)."""
+    import threading
+
+    import app.cnn_super_resolution as m
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    rng = np.random.default_rng(12)
+    imgs = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((40, 56, 3), (33, 47, 3), (64, 64, 3), (40, 56, 3))]
+    serial = [m.RealESRGAN(model_name="realesrgan_anime").enhance(im) for im in imgs]
+    results = [[None] * len(imgs) for _ in range(4)]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(2):
+                for i in ((np.arange(len(imgs)) + tid) % len(imgs)):
+                    results[tid][i] = m.RealESRGAN(model_name="realesrgan_anime").enhance(imgs[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for tid in range(4):
+        for i in range(len(imgs)):
+            assert np.array_equal(results[tid][i], serial[i]), (tid, i)
