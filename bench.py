@@ -63,6 +63,57 @@ def cpu_baseline(seed_tiles: np.ndarray) -> dict:
                       f"{dt:.2f} s/tile", "s_per_tile": round(dt, 3)}
 
 
+class ClockSampler:
+    """Reads the GPU's hwmon sclk / socket power from sysfs every 50 ms while the timed region runs
+    (diagnostic: the part sits at its power cap).  Silent when sysfs is not readable."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.files = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thr = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw and os.path.exists(hw[0] + "/freq1_input"):
+                self.files = (hw[0] + "/freq1_input", hw[0] + "/power1_input")
+        except Exception:
+            self.files = None
+        self._threading = threading
+
+    def _run(self):
+        while not self._stop.wait(0.05):
+            try:
+                f = int(open(self.files[0]).read())
+                try:
+                    w = int(open(self.files[1]).read())
+                except Exception:
+                    w = 0
+                self.samples.append((f, w))
+            except Exception:
+                return
+
+    def start(self):
+        if self.files:
+            self._thr = self._threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thr:
+            self._thr.join(timeout=1.0)
+        if not self.samples:
+            return None
+        fs = [f for f, _ in self.samples]
+        ws = [w for _, w in self.samples if w]
+        return {"sclk_mhz": round(sum(fs) / len(fs) / 1e6, 1), "power_w": round(sum(ws) / len(ws) / 1e6, 1) if ws else None,
+                "samples": len(fs)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,12 +189,16 @@ def main():
     eng.reset_kernel_stats()
     torch.cuda.synchronize()
     barrier()
+    sampler = ClockSampler(local) if rank == 0 else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    clocks = sampler.stop() if sampler else None
     stats = eng.kernel_stats()
     eng.set_profiling(0)
     if dist is not None:
@@ -198,6 +253,9 @@ def main():
                                           "alg_GB_per_s": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else 0}
                                       for k, v in stats.items() if v["launches"]}},
         }
+        if clocks:   # what the cap leaves: the same dense peak at the clock the part actually held
+            pk = MFMA_F16_PEAK_TFLOPS * clocks["sclk_mhz"] / 2400.0
+            line["roofline"]["held_clock"] = dict(clocks, peak_at_clock=round(pk, 1), frac_at_clock=round(achieved / pk, 4))
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tiles_np)
         print(json.dumps(line), flush=True)
