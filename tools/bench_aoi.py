@@ -15,7 +15,7 @@ from s2sr.weights import synthetic_state_dict  # noqa: E402
 e = native.Engine(num_block=23, precision=native.PREC_F16_HP)
 e.load_state_dict(synthetic_state_dict(23, seed=0))
 rng = np.random.default_rng(4321)
-for side in (1024, 2048):
+for side in ([int(a) for a in sys.argv[1:]] or [1024, 2048]):
     img = rng.integers(0, 256, (side, side, 3), dtype=np.uint8)
     for tile in (256, 512):
         nwin = len(native.plan_tiles(side, side, tile, 10))
