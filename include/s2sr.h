@@ -155,6 +155,11 @@ int  s2sr_synchronize(s2sr_handle* h);
  * stream and profiling runs use direct launches).  Counters since s2sr_create. */
 int  s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays);
 
+/* host-only codec for the file glue around the path (reference reads LZW GeoTIFFs through rasterio,
+ * server/app/wow_sr.py:59-79): TIFF-flavoured LZW (MSB-first 9..12-bit codes, early change).  Decodes
+ * at most `cap` bytes into dst, *out_n = bytes produced. */
+int  s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+
 /* test hook (host only, no GPU): the OCP e4m3fn encoder the weight packer uses for the fp8
  * correction stages -- round to nearest even, saturating at +-448, NaN -> 0x7f. */
 uint8_t s2sr_debug_f32_to_e4m3(float v);

@@ -82,6 +82,7 @@ _PROTOS = {
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
     "s2sr_debug_f32_to_e4m3": (C.c_uint8, [C.c_float]),
+    "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
@@ -111,6 +112,17 @@ def load_library():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def tiff_lzw_decode(data: bytes, expected: int) -> bytes:
+    """Host call (no GPU): TIFF LZW strip/tile -> raw bytes (at most `expected`)."""
+    lib = load_library()
+    out = C.create_string_buffer(max(int(expected), 1))
+    n = C.c_size_t(0)
+    rc = lib.s2sr_tiff_lzw_decode(data, len(data), out, int(expected), C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_tiff_lzw_decode: {_ERR.get(rc, rc)}")
+    return out.raw[:n.value]
 
 
 def plan_tiles(H: int, W: int, tile: int = 256, pad: int = 10, scale: int = 4) -> List[Window]:

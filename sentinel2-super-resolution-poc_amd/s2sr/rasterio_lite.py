@@ -4,8 +4,9 @@ are not required).  Covers what the reference does around the operator
 PIL decodes) as uint8 RGB, carry the georeferencing tags, write an LZW GeoTIFF whose pixel
 size is divided by the SR scale, write a PNG.
 
-Supported inputs: 8-bit RGB/RGBA/gray images of any PIL format; 16-bit single-band TIFF.
-Multi-band 16-bit TIFFs need a real TIFF library and raise a clear error here.
+Supported inputs: any image PIL decodes (8-bit RGB/RGBA/gray, 16-bit single band), and -- through
+`tiff_lite` -- the multi-band 8/16/32-bit GeoTIFFs PIL refuses (Sentinel-2 deliveries: 4+ bands of
+uint16, strips or tiles, LZW / Deflate / none, predictor 2, classic or BigTIFF).
 """
 from __future__ import annotations
 
@@ -70,12 +71,27 @@ def read_rgb_u8(path: Path, minmax_eps: float = 0.0) -> Tuple[np.ndarray, Option
     mirroring the reference's suffix switch (wow_sr.py:59,77-79)."""
     path = Path(path)
     is_tif = path.suffix.lower() in (".tif", ".tiff")
+    pil_error = None
+    if is_tif:
+        # TIFFs go through tiff_lite first: like rasterio it returns the raw band values (PIL quietly
+        # squeezes 3/4-band uint16 files to 8 bits and refuses more bands); PIL is the fallback for
+        # layouts tiff_lite does not decode (JPEG-in-TIFF, ...)
+        from . import tiff_lite
+        try:
+            arr, tv = tiff_lite.read_tiff(path)
+        except tiff_lite.TiffError as e:
+            pil_error = e
+        else:
+            # bands 1-3, or the single band three times (wow_sr.py:61-65)
+            arr = arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2)
+            georef = GeoRef({t: (tv[t][0] if t == TAG_GEOASCII else tuple(tv[t])) for t in _GEO_TAGS if t in tv})
+            return np.ascontiguousarray(_to_u8(arr, minmax_eps)), georef
     try:
         im = Image.open(path)
         im.load()
-    except Exception as e:      # PIL cannot decode e.g. 3-band uint16 GeoTIFFs
-        raise ValueError(f"{path}: unsupported raster layout for the PIL reader ({e}); convert to 8-bit RGB "
-                         f"or single-band 16-bit, or install rasterio and read it upstream") from e
+    except Exception as e:
+        raise ValueError(f"{path}: unsupported raster layout (PIL: {e}"
+                         + (f"; tiff_lite: {pil_error}" if pil_error else "") + ")") from e
     georef = None
     if is_tif:
         tags = {}

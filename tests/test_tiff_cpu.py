@@ -1,0 +1,165 @@
+"""CPU tests of the raster input glue: the TIFF reader that takes over where PIL stops (multi-band
+16-bit GeoTIFFs, the reference reads them with rasterio, server/app/wow_sr.py:59-79) and the
+native TIFF-LZW decoder.  Files are produced by PIL where PIL can write them and by a small
+writer below (strips / tiles, chunky / planar, Deflate + predictor, big endian, BigTIFF)."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from s2sr import rasterio_lite as rio
+from s2sr import tiff_lite
+
+
+def _write_tiff(path, arr, bo="<", big=False, tile=None, comp=1, pred=1, planar=1, extra=()):
+    """arr [H, W, B] (u8/u16/i16/f32).  extra: iterable of (tag, type, values) geo tags."""
+    H, W, B = arr.shape
+    dt = arr.dtype.newbyteorder(bo)
+    fmt = {"u": 1, "i": 2, "f": 3}[arr.dtype.kind]
+    cw, ch = (tile, tile) if tile else (W, 16)
+    nx, ny = (W + cw - 1) // cw, (H + ch - 1) // ch
+    chunks = []
+    for pl in range(B if planar == 2 else 1):
+        for iy in range(ny):
+            for ix in range(nx):
+                rows = ch if tile else min(ch, H - iy * ch)
+                blk = np.zeros((rows, cw, 1 if planar == 2 else B), arr.dtype)
+                src = arr[iy * ch:iy * ch + rows, ix * cw:ix * cw + cw, pl:pl + 1] if planar == 2 else \
+                    arr[iy * ch:iy * ch + rows, ix * cw:ix * cw + cw, :]
+                blk[:src.shape[0], :src.shape[1]] = src
+                if pred == 2:
+                    d = blk.copy()
+                    d[:, 1:] = blk[:, 1:] - blk[:, :-1]          # wraps modulo the sample width
+                    blk = d
+                raw = blk.astype(dt).tobytes()
+                chunks.append(zlib.compress(raw) if comp == 8 else raw)
+    hdr = 16 if big else 8
+    offs, pos = [], hdr
+    for c in chunks:
+        offs.append(pos)
+        pos += len(c) + (len(c) & 1)
+    ent = [(256, 4, (W,)), (257, 4, (H,)), (258, 3, (arr.dtype.itemsize * 8,) * B), (259, 3, (comp,)),
+           (262, 3, (2 if B >= 3 else 1,)), (277, 3, (B,)), (284, 3, (planar,)), (317, 3, (pred,)), (339, 3, (fmt,) * B)]
+    o_t, c_t = (324, 325) if tile else (273, 279)
+    big_t = 16 if big else 4
+    ent += [(o_t, big_t, tuple(offs)), (c_t, big_t, tuple(len(c) for c in chunks))]
+    ent += [(322, 3, (cw,)), (323, 3, (ch,))] if tile else [(278, 3, (ch,))]
+    ent += list(extra)
+    ent.sort()
+    tsz = {3: ("H", 2), 4: ("I", 4), 12: ("d", 8), 16: ("Q", 8), 2: ("s", 1)}
+    esz, inl = (20, 8) if big else (12, 4)
+    ifd_off = pos
+    val_pos = ifd_off + (8 if big else 2) + esz * len(ent) + (8 if big else 4)
+    ifd, tail = b"", b""
+    for tag, typ, vals in ent:
+        if typ == 2:
+            data = vals.encode() + b"\0"
+            cnt = len(data)
+        else:
+            f, _ = tsz[typ]
+            data = struct.pack(bo + f * len(vals), *vals)
+            cnt = len(vals)
+        e = struct.pack(bo + "HH", tag, typ) + struct.pack(bo + ("Q" if big else "I"), cnt)
+        if len(data) <= inl:
+            e += data.ljust(inl, b"\0")
+        else:
+            e += struct.pack(bo + ("Q" if big else "I"), val_pos + len(tail))
+            tail += data + (b"\0" if len(data) & 1 else b"")
+        ifd += e
+    with open(path, "wb") as f:
+        f.write(b"II" if bo == "<" else b"MM")
+        if big:
+            f.write(struct.pack(bo + "HHHQ", 43, 8, 0, ifd_off))
+        else:
+            f.write(struct.pack(bo + "HI", 42, ifd_off))
+        for c in chunks:
+            f.write(c + (b"\0" if len(c) & 1 else b""))
+        f.write(struct.pack(bo + ("Q" if big else "H"), len(ent)) + ifd + struct.pack(bo + ("Q" if big else "I"), 0) + tail)
+
+
+def _scene(H, W, B, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = (np.sin(xx / 9.0) + np.cos(yy / 7.0) + 2.2) * (900 if np.dtype(dtype).itemsize > 1 else 50)
+    a = np.stack([base * (1 + 0.1 * b) + rng.integers(0, 40, (H, W)) for b in range(B)], -1)
+    return a.astype(dtype)
+
+
+@pytest.mark.parametrize("mode", ["rgb8", "i16", "rgb8_noise"])
+def test_lzw_against_pil(tmp_path, mode):
+    """PIL writes the LZW file, the native decoder (through tiff_lite) must return PIL's own pixels.
+    The noise image forces the code table through every width and several ClearCodes."""
+    if mode == "rgb8":
+        arr = _scene(150, 211, 3, np.uint8)
+        im = Image.fromarray(arr, "RGB")
+    elif mode == "rgb8_noise":
+        arr = np.random.default_rng(5).integers(0, 256, (120, 333, 3), dtype=np.uint8)
+        im = Image.fromarray(arr, "RGB")
+    else:
+        arr = _scene(97, 130, 1, np.uint16)[..., 0]
+        im = Image.fromarray(arr)
+    p = tmp_path / f"{mode}.tif"
+    im.save(p, format="TIFF", compression="tiff_lzw")
+    got, tags = tiff_lite.read_tiff(p)
+    assert tags[tiff_lite.COMPRESSION][0] == 5
+    want = np.asarray(Image.open(p))
+    assert np.array_equal(got if got.shape[2] > 1 else got[..., 0], want)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                             # chunky strips, uncompressed, little endian
+    dict(comp=8, pred=2),                               # Deflate + horizontal differencing
+    dict(tile=64, comp=8, pred=2),                      # tiled (edge tiles padded)
+    dict(planar=2, comp=8),                             # separate planes
+    dict(bo=">", tile=32),                              # big endian, tiled
+    dict(big=True, comp=8, pred=2, tile=128),           # BigTIFF
+])
+def test_multiband_uint16_roundtrip(tmp_path, kw):
+    arr = _scene(143, 201, 4, np.uint16, seed=3)        # 4 bands like a B02/B03/B04/B08 delivery
+    p = tmp_path / "s2.tif"
+    _write_tiff(p, arr, **kw)
+    got, _ = tiff_lite.read_tiff(p)
+    assert got.dtype == np.uint16 and np.array_equal(got, arr)
+
+
+def test_other_sample_types_and_errors(tmp_path):
+    for dt in (np.uint8, np.int16, np.float32):
+        arr = _scene(40, 50, 3, dt, seed=1)
+        _write_tiff(tmp_path / "t.tif", arr, comp=8, pred=(1 if np.dtype(dt).kind == "f" else 2))
+        got, _ = tiff_lite.read_tiff(tmp_path / "t.tif")
+        assert got.dtype == np.dtype(dt) and np.array_equal(got, arr)
+    (tmp_path / "bad.tif").write_bytes(b"not a tiff at all")
+    with pytest.raises(tiff_lite.TiffError):
+        tiff_lite.read_tiff(tmp_path / "bad.tif")
+    _write_tiff(tmp_path / "jpeg.tif", _scene(16, 16, 3, np.uint8), comp=1)
+    raw = bytearray((tmp_path / "jpeg.tif").read_bytes())
+    raw = raw.replace(struct.pack("<HHI", 259, 3, 1) + struct.pack("<H", 1), struct.pack("<HHI", 259, 3, 1) + struct.pack("<H", 7))
+    (tmp_path / "jpeg.tif").write_bytes(bytes(raw))
+    with pytest.raises(tiff_lite.TiffError, match="compression 7"):
+        tiff_lite.read_tiff(tmp_path / "jpeg.tif")
+
+
+def test_read_rgb_u8_on_sentinel_like_geotiff(tmp_path):
+    """What apply_wow_sr does with a 4-band uint16 GeoTIFF (wow_sr.py:59-79): bands 1-3, one min-max
+    over the 3-band stack to 0..255 (truncating), geo tags carried to the x4 output."""
+    arr = _scene(90, 120, 4, np.uint16, seed=7)
+    arr[..., 3] += 20000                                   # band 4 (NIR) must not influence the stretch
+    geo = [(33550, 12, (10.0, 10.0, 0.0)), (33922, 12, (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0)),
+           (34735, 3, (1, 1, 0, 1, 3072, 0, 1, 32633)), (34737, 2, "WGS 84 / UTM zone 33N|")]
+    p = tmp_path / "aoi.tif"
+    _write_tiff(p, arr, tile=64, comp=8, pred=2, extra=geo)
+    # the reason tiff_lite goes first: PIL squeezes this file to 8-bit RGBA without a word
+    assert np.asarray(Image.open(p)).dtype == np.uint8
+    rgb, georef = rio.read_rgb_u8(p)
+    img = arr[..., :3]
+    want = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)   # the reference's expression
+    assert rgb.dtype == np.uint8 and np.array_equal(rgb, want)
+    assert georef.pixel_size == (10.0, 10.0)
+    assert georef.scaled(4).pixel_size == (2.5, 2.5)
+    out = tmp_path / "out.tif"
+    rio.write_geotiff_rgb(out, np.repeat(np.repeat(rgb, 4, 0), 4, 1), georef.scaled(4))
+    back, g2 = rio.read_rgb_u8(out)
+    assert back.shape == (360, 480, 3) and g2.pixel_size == (2.5, 2.5)
+    assert tuple(g2.tags[33922]) == (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0)
