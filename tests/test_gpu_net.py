@@ -320,3 +320,30 @@ def test_banded_mosaic_path_matches_single_pass():
         print(f"banded {H}x{W}: {nwin} windows, u8 vs oracle identical {np.mean(d == 0):.4f}, vs own float {np.mean(q == qf):.4f}")
         assert d.max() <= 1 and np.mean(d == 0) >= 0.98
         assert np.array_equal(q, qf)
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] at full size (32 tiles of 256x256, 23 blocks, HP): size-independent
+    properties instead of an oracle run -- a permuted batch gives the permuted outputs, repeated tiles
+    give identical bytes, a second run is bit-identical, the group size does not matter, and two
+    tiles spot-checked against single-tile runs."""
+    from s2sr.synth import synthetic_tiles
+
+    nb, B = 23, 32
+    tiles = synthetic_tiles(B, 256, seed=1234)
+    tiles[17] = tiles[3]                      # a repeated tile
+    e = engine(nb, native.PREC_F16_HP)
+    y = e.forward_batch_u8(tiles)
+    assert y.shape == (B, 1024, 1024, 3)
+    assert np.array_equal(y[17], y[3])
+    assert np.array_equal(e.forward_batch_u8(tiles), y)
+    perm = np.random.default_rng(0).permutation(B)
+    assert np.array_equal(e.forward_batch_u8(tiles[perm]), y[perm])
+    for i in (0, 31):
+        assert np.array_equal(e.forward_batch_u8(tiles[i:i + 1])[0], y[i])
+    e8 = native.Engine(num_block=nb, group=8, precision=native.PREC_F16_HP)
+    e8.load_state_dict(synthetic_state_dict(nb, seed=0))
+    assert np.array_equal(e8.forward_batch_u8(tiles), y)
+    e8.close()
+    # outputs are images, not saturated garbage: every tile uses a wide range of values
+    assert all(np.unique(y[i]).size > 64 for i in range(0, B, 5))
