@@ -143,6 +143,24 @@ int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t 
 int  s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
                                    const s2sr_pp_params* prm, void* d_out, void* stream);
 
+/* ---- XYZ tile pyramid: the step after the path (reference server/app/tiling.py:102-186 shells out to
+ * `gdalwarp -t_srs EPSG:3857 -r bilinear` and `gdal2tiles.py --xyz --resampling average`).  The geometry
+ * (projection, tile bounds, footprints) is resolved by the caller into tables; tile arrays are
+ * [rows north to south][columns][256][256][4] RGBA u8, alpha 0 = no data.
+ * warp: grid = float32 [gh][gw][2], the source (column, row) in pixel-centre coordinates at every
+ *   `step`-th output pixel (step a power of two, (gh-1)*step >= OH-1); bilinear with edge replication,
+ *   alpha = 255 inside the source raster.
+ * base: tile pixel = rounded mean of the source pixels with alpha > 0 in columns col_lo..col_hi and
+ *   rows row_lo..row_hi (tables of nx*256 and ny*256 entries, lo > hi = empty).
+ * overview: parent pixel = rounded mean of the valid pixels of its 2x2 group in the child array;
+ *   (ox, oy) = child-array tile coordinates of the first parent tile's north-west child (may be -1). */
+int  s2sr_warp_bilinear_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, const float* grid, int32_t gh, int32_t gw,
+                           int32_t step, int32_t OH, int32_t OW, uint8_t* out_rgba);
+int  s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W, const int32_t* col_lo, const int32_t* col_hi,
+                        const int32_t* row_lo, const int32_t* row_hi, int32_t nx, int32_t ny, uint8_t* out);
+int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, int32_t cny, int32_t ox, int32_t oy, int32_t pnx,
+                            int32_t pny, uint8_t* out);
+
 /* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;
  * on = N >= 1: every N-th launch of each family is bracketed by a hipEvent pair (N > 1 keeps
  * the event overhead out of a timed region; stats then cover the sampled launches only). */

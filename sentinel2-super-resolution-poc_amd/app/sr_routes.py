@@ -6,8 +6,10 @@ request fields, validation codes, job-table fields and status strings
 the GPU path in tests; it is NOT a port of the server.  Out of scope and therefore hooks:
   * imagery fetch (reference smart_fetch.ensure_best_image, network): `fetcher` callback, absent
     -> a job that needs it fails with a clear message, like any other exception in the reference;
-  * XYZ tiling (reference tiling.process_raster_to_tiles, GDAL subprocesses): `tiler` callback,
-    absent -> the tiling stage is a no-op and `result["tiles_dir"]` is not set.
+  * XYZ tiling (reference tiling.process_raster_to_tiles, GDAL subprocesses): `tiler` callback;
+    the default is this build's GPU pyramid (app.tiling.process_raster_to_tiles) with the reference's
+    zoom range for SR output (settings.tile_min_zoom = 10 .. min(tile_max_zoom + 2, 20) = 18,
+    settings.py:31-32, main.py:272-277); pass `tiler=False` to skip the stage.
 """
 from __future__ import annotations
 
@@ -41,8 +43,8 @@ class SRResponse(BaseModel):         # main.py:230-235
     message: str
 
 
-def create_app(data_dir: Path, source_dir: Optional[Path] = None,
-               fetcher: Optional[Callable] = None, tiler: Optional[Callable] = None) -> FastAPI:
+def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optional[Callable] = None, tiler=None,
+               tile_min_zoom: int = 10, tile_max_zoom: int = 16) -> FastAPI:
     app = FastAPI(title="s2sr SR handler harness")
     data_dir = Path(data_dir)
     source_dir = Path(source_dir) if source_dir else data_dir / "source"
@@ -58,11 +60,17 @@ def create_app(data_dir: Path, source_dir: Optional[Path] = None,
         tifs = sorted(source_dir.glob("*.tif"), key=lambda x: x.stat().st_mtime, reverse=True)
         return tifs[0] if tifs else None
 
+    def _default_tiler(sr_tif, tiles_dir):
+        from app.tiling import process_raster_to_tiles
+        process_raster_to_tiles(input_path=sr_tif, tiles_dir=tiles_dir, min_zoom=tile_min_zoom,
+                                max_zoom=min(tile_max_zoom + 2, 20))          # "Higher zoom for SR" (main.py:276)
+
     def _tile(result, sub):
         sr_tif = result["outputs"].get("sr_tif")
-        if tiler and sr_tif and Path(sr_tif).exists():
+        run = _default_tiler if tiler is None else tiler
+        if run and sr_tif and Path(sr_tif).exists():
             tiles_dir = data_dir / sub
-            tiler(Path(sr_tif), tiles_dir)
+            run(Path(sr_tif), tiles_dir)
             result["tiles_dir"] = str(tiles_dir)
 
     def run_sr_job(job_id, input_file, scale, model, output_dir):          # main.py:247-287

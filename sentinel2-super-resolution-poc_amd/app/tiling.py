@@ -1,0 +1,194 @@
+"""Reprojection to Web Mercator and XYZ tile generation on the GPU: the same module surface as the
+reference's GDAL helpers (reference server/app/tiling.py: RasterInfo :14-25, get_raster_info :28-99,
+reproject_to_web_mercator :102-135, generate_xyz_tiles :138-186, create_tileset_metadata :189-224,
+process_raster_to_tiles :227-275), without gdalinfo / gdalwarp / gdal2tiles.py subprocesses.
+
+Scope: 8-bit RGB rasters (what the SR path writes) in UTM (EPSG:326xx / 327xx), EPSG:4326 or
+EPSG:3857, north-up.  Resampling definitions are this build's (s2sr/tiles.py, csrc/tiles.hip);
+GDAL is not available to compare against, see DESIGN.md.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import struct
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+from PIL import Image
+
+from s2sr import geo, native, tiles
+from s2sr import rasterio_lite as rio
+from s2sr import tiff_lite
+
+logger = logging.getLogger("tiling")
+
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def encode_png_rgba(tile: np.ndarray, level: int = 3) -> bytes:
+    """256x256x4 uint8 -> PNG bytes (8-bit RGBA, Sub filter on every row, one IDAT).  Plain zlib calls,
+    which release the GIL: tiles are encoded on a thread pool (gdal2tiles uses --processes 4 for this)."""
+    h, w, _ = tile.shape
+    rows = tile.reshape(h, w * 4)
+    sub = rows.copy()
+    sub[:, 4:] = rows[:, 4:] - rows[:, :-4]                    # PNG filter type 1, bpp = 4 (wraps modulo 256)
+    raw = np.empty((h, w * 4 + 1), np.uint8)
+    raw[:, 0] = 1
+    raw[:, 1:] = sub
+
+    def chunk(kind: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+
+    return (_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw.tobytes(), level)) + chunk(b"IEND", b""))
+
+_ENGINE: Optional[native.Engine] = None
+
+
+def _engine() -> native.Engine:
+    """A weightless handle is enough for the pyramid kernels (raises without a gfx950 GPU)."""
+    global _ENGINE
+    if _ENGINE is None:
+        _ENGINE = native.Engine(num_block=1)
+    return _ENGINE
+
+
+@dataclass
+class RasterInfo:
+    """Information about a raster file (field for field the reference's dataclass)."""
+    path: Path
+    crs: str
+    bounds: list          # [west, south, east, north] in native CRS
+    bounds_4326: list     # [west, south, east, north] in EPSG:4326
+    width: int
+    height: int
+    bands: int
+    dtype: str
+
+
+_GDAL_TYPE = {"uint8": "Byte", "uint16": "UInt16", "int16": "Int16", "uint32": "UInt32", "int32": "Int32",
+              "float32": "Float32", "float64": "Float64"}
+
+
+def _read(path: Path):
+    arr, tags = tiff_lite.read_tiff(path)
+    place = geo.placement_from_tags(tags)
+    if place is None:
+        raise ValueError(f"{path}: no north-up georeferencing (tiepoint + pixel scale) in the GeoTIFF tags")
+    epsg = geo.epsg_from_geokeys(tags.get(rio.TAG_GEOKEYS))
+    return arr, tags, place, geo.CRS(epsg if epsg else 4326)      # the reference defaults to EPSG:4326 too (:49)
+
+
+def get_raster_info(raster_path: Path) -> RasterInfo:
+    raster_path = Path(raster_path)
+    arr, _tags, place, crs = _read(raster_path)
+    h, w, b = arr.shape
+    west, south, east, north = place.bounds(w, h)
+    t = np.linspace(0.0, 1.0, 21)
+    ex = np.concatenate([west + (east - west) * t, np.full(21, east), east - (east - west) * t, np.full(21, west)])
+    ey = np.concatenate([np.full(21, north), north - (north - south) * t, np.full(21, south), south + (north - south) * t])
+    lon, lat = crs.to_lonlat(ex, ey)
+    return RasterInfo(path=raster_path, crs=str(crs), bounds=[west, south, east, north],
+                      bounds_4326=[float(lon.min()), float(lat.min()), float(lon.max()), float(lat.max())],
+                      width=w, height=h, bands=b, dtype=_GDAL_TYPE.get(arr.dtype.name, arr.dtype.name))
+
+
+def _mercator_tags(place: geo.Placement) -> rio.GeoRef:
+    return rio.GeoRef({rio.TAG_PIXEL_SCALE: (place.dx, place.dy, 0.0),
+                       rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, place.x0, place.y0, 0.0),
+                       rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 3857)})
+
+
+def reproject_to_web_mercator(input_path: Path, output_path: Path, resample_method: str = "bilinear") -> Path:
+    """Writes an RGB GeoTIFF on the EPSG:3857 grid (pixels outside the source are black; the tile
+    generator recomputes coverage from the geometry, so no alpha band is stored)."""
+    if resample_method != "bilinear":
+        raise ValueError("only bilinear resampling is implemented (the reference never passes anything else)")
+    input_path, output_path = Path(input_path), Path(output_path)
+    arr, _tags, place, crs = _read(input_path)
+    rgb = rio._to_u8(arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
+    plan = tiles.plan_warp(rgb.shape[1], rgb.shape[0], place, crs)
+    out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    output_path.parent.mkdir(parents=True, exist_ok=True)
+    rio.write_geotiff_rgb(output_path, np.ascontiguousarray(out[..., :3]), _mercator_tags(plan.placement))
+    logger.info("Reprojection complete: %s", output_path)
+    return output_path
+
+
+def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, max_zoom: int = 16, tile_size: int = 256,
+                       resampling: str = "average", alpha: Optional[np.ndarray] = None) -> Path:
+    """z/x/y.png (XYZ row order, RGBA) for every tile of zooms min..max that holds data."""
+    if tile_size != 256 or resampling != "average":
+        raise ValueError("tile_size 256 and average resampling are what the reference uses and what is implemented")
+    input_path, output_dir = Path(input_path), Path(output_dir)
+    arr, _tags, place, crs = _read(input_path)
+    if crs.epsg != 3857:
+        raise ValueError(f"{input_path}: {crs}, tiles are cut from an EPSG:3857 raster (reproject_to_web_mercator first)")
+    h, w = arr.shape[:2]
+    rgba = np.empty((h, w, 4), np.uint8)
+    rgba[..., :3] = arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2)
+    rgba[..., 3] = 255 if alpha is None else alpha
+    output_dir.mkdir(parents=True, exist_ok=True)
+    eng = _engine()
+    levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
+    def write_tile(args):
+        t, path = args
+        path.write_bytes(encode_png_rgba(t))
+
+    prev, prev_lv = None, None
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+        pending = []
+        for lv in levels:
+            if prev is None:
+                cur = eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h))
+            else:
+                ox, oy = tiles.overview_offsets(lv, prev_lv)
+                cur = eng.tiles_overview_u8(prev, ox, oy, lv.nx, lv.ny)
+            has_data = cur[..., 3].reshape(lv.ny, lv.nx, -1).any(-1)
+            jobs = []
+            for i in range(lv.nx):
+                if has_data[:, i].any():
+                    (output_dir / str(lv.zoom) / str(lv.tminx + i)).mkdir(parents=True, exist_ok=True)
+            for j, i in zip(*np.nonzero(has_data)):
+                jobs.append((cur[j, i], output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png"))
+            pending.append(pool.map(write_tile, jobs, chunksize=8))     # encoded while the next level is computed
+            prev, prev_lv = cur, lv
+        for p in pending:
+            list(p)                                                     # surface any exception
+    logger.info("Tile generation complete: %s", output_dir)
+    return output_dir
+
+
+def create_tileset_metadata(tiles_dir: Path, bounds_4326: list, min_zoom: int, max_zoom: int,
+                            tile_template: str = "/tiles/{z}/{x}/{y}.png") -> dict:
+    metadata = {"bounds": bounds_4326, "minzoom": min_zoom, "maxzoom": max_zoom, "tileTemplate": tile_template,
+                "attribution": "Sentinel-2 SR via UP42", "format": "png", "tileSize": 256}
+    tiles_dir = Path(tiles_dir)
+    tiles_dir.mkdir(parents=True, exist_ok=True)
+    (tiles_dir / "tileset.json").write_text(json.dumps(metadata, indent=2))
+    return metadata
+
+
+def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 10, max_zoom: int = 16) -> dict:
+    """Check the CRS, reproject if needed, cut the pyramid, write tileset.json."""
+    input_path, tiles_dir = Path(input_path), Path(tiles_dir)
+    info = get_raster_info(input_path)
+    alpha = None
+    if info.crs != "EPSG:3857":
+        working = input_path.parent / f"{input_path.stem}_3857.tif"
+        arr, _tags, place, crs = _read(input_path)
+        rgb = rio._to_u8(arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
+        plan = tiles.plan_warp(rgb.shape[1], rgb.shape[0], place, crs)
+        out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+        rio.write_geotiff_rgb(working, np.ascontiguousarray(out[..., :3]), _mercator_tags(plan.placement))
+        alpha = out[..., 3]
+    else:
+        working = input_path
+    generate_xyz_tiles(working, tiles_dir, min_zoom=min_zoom, max_zoom=max_zoom, alpha=alpha)
+    return create_tileset_metadata(tiles_dir, info.bounds_4326, min_zoom, max_zoom)

@@ -918,6 +918,84 @@ int s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W
     return S2SR_OK;
 }
 
+// ---- XYZ tile pyramid (host buffers in and out; geometry tables come from the caller) ---------------
+int s2sr_warp_bilinear_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, const float* grid, int32_t gh, int32_t gw,
+                          int32_t step, int32_t OH, int32_t OW, uint8_t* out_rgba) {
+    if (!h || !rgb || !grid || !out_rgba || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || gh <= 0 || gw <= 0) return S2SR_E_INVALID;
+    if (step <= 0 || (step & (step - 1))) return fail(h, S2SR_E_INVALID, "warp node spacing must be a power of two");
+    if ((int64_t)(gh - 1) * step < OH - 1 || (int64_t)(gw - 1) * step < OW - 1)
+        return fail(h, S2SR_E_INVALID, "warp node grid does not cover the output raster");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const size_t ib = (size_t)H * W * 3, gb = (size_t)gh * gw * 8, ob = (size_t)OH * OW * 4;
+    int rc;
+    if ((rc = ensure_scratch(h, 0, ib))) return rc;
+    if ((rc = ensure_scratch(h, 1, ob))) return rc;
+    if ((rc = ensure_scratch(h, 3, gb))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgb, ib, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[3], grid, gb, hipMemcpyHostToDevice, st));
+    {
+        Scope sc(h, st, F_MISC, 0.0, (double)ob + (double)OH * OW * 12.0);
+        HIPCHK(h, launch_warp_bilinear((const uint8_t*)h->d_scratch[0], H, W, (const float*)h->d_scratch[3], gh, gw, step, OH, OW,
+                                       (uint8_t*)h->d_scratch[1], st));
+    }
+    HIPCHK(h, hipMemcpyAsync(out_rgba, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return S2SR_OK;
+}
+
+int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W, const int32_t* col_lo, const int32_t* col_hi,
+                       const int32_t* row_lo, const int32_t* row_hi, int32_t nx, int32_t ny, uint8_t* out) {
+    if (!h || !rgba || !col_lo || !col_hi || !row_lo || !row_hi || !out || H <= 0 || W <= 0 || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
+    for (int i = 0; i < nx * 256; ++i)
+        if (col_lo[i] < 0 || col_hi[i] >= W) return fail(h, S2SR_E_INVALID, "column footprint table leaves the raster");
+    for (int i = 0; i < ny * 256; ++i)
+        if (row_lo[i] < 0 || row_hi[i] >= H) return fail(h, S2SR_E_INVALID, "row footprint table leaves the raster");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const size_t ib = (size_t)H * W * 4, ob = (size_t)nx * ny * 65536 * 4, cb = (size_t)nx * 256 * 4, rb = (size_t)ny * 256 * 4;
+    int rc;
+    if ((rc = ensure_scratch(h, 0, ib))) return rc;
+    if ((rc = ensure_scratch(h, 1, ob))) return rc;
+    if ((rc = ensure_scratch(h, 3, 2 * cb + 2 * rb))) return rc;
+    int32_t* t = (int32_t*)h->d_scratch[3];
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgba, ib, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(t, col_lo, cb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(t + nx * 256, col_hi, cb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(t + 2 * nx * 256, row_lo, rb, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(t + 2 * nx * 256 + ny * 256, row_hi, rb, hipMemcpyHostToDevice, st));
+    {
+        Scope sc(h, st, F_MISC, 0.0, (double)ib + (double)ob);
+        HIPCHK(h, launch_tiles_base((const uint8_t*)h->d_scratch[0], W, t, t + nx * 256, t + 2 * nx * 256, t + 2 * nx * 256 + ny * 256, nx,
+                                    ny, (uint8_t*)h->d_scratch[1], st));
+    }
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return S2SR_OK;
+}
+
+int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, int32_t cny, int32_t ox, int32_t oy, int32_t pnx,
+                           int32_t pny, uint8_t* out) {
+    if (!h || !child || !out || cnx <= 0 || cny <= 0 || pnx <= 0 || pny <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const size_t ib = (size_t)cnx * cny * 65536 * 4, ob = (size_t)pnx * pny * 65536 * 4;
+    int rc;
+    if ((rc = ensure_scratch(h, 0, ib))) return rc;
+    if ((rc = ensure_scratch(h, 1, ob))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], child, ib, hipMemcpyHostToDevice, st));
+    {
+        Scope sc(h, st, F_MISC, 0.0, (double)ib + (double)ob);
+        HIPCHK(h, launch_tiles_overview((const uint8_t*)h->d_scratch[0], cnx, cny, ox, oy, pnx, pny, (uint8_t*)h->d_scratch[1], st));
+    }
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return S2SR_OK;
+}
+
 int s2sr_set_profiling(s2sr_handle* h, int32_t on) {
     if (!h) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);

@@ -93,6 +93,14 @@ size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
 void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host);
 uint8_t f32_to_e4m3(float f);   // OCP e4m3fn, round to nearest even, saturating at +-448
 
+// XYZ tile pyramid (tiles.hip)
+hipError_t launch_warp_bilinear(const uint8_t* d_rgb, int H, int W, const float* d_grid, int gh, int gw, int step, int OH, int OW,
+                                uint8_t* d_out, hipStream_t st);
+hipError_t launch_tiles_base(const uint8_t* d_rgba, int W, const int32_t* d_col_lo, const int32_t* d_col_hi, const int32_t* d_row_lo,
+                             const int32_t* d_row_hi, int nx, int ny, uint8_t* d_out, hipStream_t st);
+hipError_t launch_tiles_overview(const uint8_t* d_child, int cnx, int cny, int ox, int oy, int pnx, int pny, uint8_t* d_out,
+                                 hipStream_t st);
+
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);
 hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB,

@@ -82,6 +82,10 @@ _PROTOS = {
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
     "s2sr_debug_f32_to_e4m3": (C.c_uint8, [C.c_float]),
+    "s2sr_warp_bilinear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_tiles_base_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_tiles_overview_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
     "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
@@ -266,6 +270,31 @@ class Engine:
         self._check(self._lib.s2sr_get_kernel_stats(self._h, arr, n.value, C.byref(n)), "s2sr_get_kernel_stats")
         return {s.name.decode(): {"launches": s.launches, "total_ms": s.total_ms, "flops": s.flops, "bytes": s.bytes}
                 for s in arr}
+
+    # -- XYZ tile pyramid -----------------------------------------------------------------
+    def warp_bilinear_u8(self, rgb: np.ndarray, grid: np.ndarray, step: int, out_h: int, out_w: int) -> np.ndarray:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        grid = np.ascontiguousarray(grid, np.float32)
+        out = np.empty((out_h, out_w, 4), np.uint8)
+        self._check(self._lib.s2sr_warp_bilinear_u8(self._h, _ptr(rgb), rgb.shape[0], rgb.shape[1], _ptr(grid), grid.shape[0],
+                                                    grid.shape[1], step, out_h, out_w, _ptr(out)), "s2sr_warp_bilinear_u8")
+        return out
+
+    def tiles_base_u8(self, rgba: np.ndarray, col_lo, col_hi, row_lo, row_hi) -> np.ndarray:
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        t = [np.ascontiguousarray(a, np.int32) for a in (col_lo, col_hi, row_lo, row_hi)]
+        nx, ny = t[0].size // 256, t[2].size // 256
+        out = np.empty((ny, nx, 256, 256, 4), np.uint8)
+        self._check(self._lib.s2sr_tiles_base_u8(self._h, _ptr(rgba), rgba.shape[0], rgba.shape[1], _ptr(t[0]), _ptr(t[1]), _ptr(t[2]),
+                                                 _ptr(t[3]), nx, ny, _ptr(out)), "s2sr_tiles_base_u8")
+        return out
+
+    def tiles_overview_u8(self, child: np.ndarray, ox: int, oy: int, pnx: int, pny: int) -> np.ndarray:
+        child = np.ascontiguousarray(child, np.uint8)
+        out = np.empty((pny, pnx, 256, 256, 4), np.uint8)
+        self._check(self._lib.s2sr_tiles_overview_u8(self._h, _ptr(child), child.shape[1], child.shape[0], ox, oy, pnx, pny, _ptr(out)),
+                    "s2sr_tiles_overview_u8")
+        return out
 
     def synchronize(self):
         self._check(self._lib.s2sr_synchronize(self._h), "s2sr_synchronize")

@@ -1,0 +1,142 @@
+"""GPU parity of the tile-pyramid kernels (through the C ABI) against the numpy oracle -- bit exact:
+integer means, and float32 bilinear steps in a fixed order -- plus the module-level pipeline
+(reference surface server/app/tiling.py:227-275) on a synthetic UTM GeoTIFF."""
+import json
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import tiles_ref as ref
+from s2sr import geo, native, tiles
+from s2sr import rasterio_lite as rio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = native.Engine(num_block=1)
+    yield e
+    e.close()
+
+
+def _scene(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([120 + 90 * np.sin(xx / 11.0 + c) * np.cos(yy / 7.0) + rng.integers(-15, 16, (h, w)) for c in range(3)], -1)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("epsg,origin", [(32633, (600000.0, 5100000.0)), (32733, (300000.0, 6200000.0)), (4326, (13.3, 52.6))])
+def test_warp_bit_exact(eng, epsg, origin):
+    rgb = _scene(150, 211, seed=epsg)
+    px = 2.5 if epsg != 4326 else 2.5e-5
+    plan = tiles.plan_warp(211, 150, geo.Placement(origin[0], origin[1], px, px), geo.CRS(epsg))
+    got = eng.warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    want = ref.warp_bilinear(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    assert got.shape == (plan.out_h, plan.out_w, 4)
+    assert np.array_equal(got, want), int((got != want).sum())
+    cover = got[..., 3].mean() / 255
+    assert 0.9 < cover <= 1.0                                   # the warped outline leaves thin empty wedges at most
+    with pytest.raises(native.S2srError):
+        eng.warp_bilinear_u8(rgb, plan.grid, 12, plan.out_h, plan.out_w)       # node spacing must be a power of two
+    with pytest.raises(native.S2srError):
+        eng.warp_bilinear_u8(rgb, plan.grid[:-1], plan.step, plan.out_h, plan.out_w)   # grid too small for the output
+
+
+def test_base_and_overview_bit_exact(eng):
+    rng = np.random.default_rng(9)
+    rgba = np.concatenate([_scene(300, 420, seed=2), np.full((300, 420, 1), 255, np.uint8)], -1)
+    rgba[..., 3] = np.where(rng.random((300, 420)) < 0.15, 0, 255)
+    place = geo.Placement(1500017.3, 5999994.9, 3.1, 3.1)
+    levels = tiles.plan_levels(place.bounds(420, 300), 12, 15)
+    base = eng.tiles_base_u8(rgba, *tiles.plan_base(levels[0], place, 420, 300))
+    lv = levels[0]
+    assert base.shape == (lv.ny, lv.nx, 256, 256, 4)
+    for j, i in ((0, 0), (lv.ny - 1, lv.nx - 1)):
+        want = ref.base_tile(rgba, place.x0, place.y0, place.dx, place.dy, lv.tminx + i, lv.tmaxy - j, lv.zoom)
+        assert np.array_equal(base[j, i], want)
+    cur, cur_lv = base, lv
+    for nxt in levels[1:]:
+        ox, oy = tiles.overview_offsets(nxt, cur_lv)
+        got = eng.tiles_overview_u8(cur, ox, oy, nxt.nx, nxt.ny)
+        assert np.array_equal(got, ref.overview(cur, ox, oy, nxt.nx, nxt.ny)), nxt.zoom
+        cur, cur_lv = got, nxt
+    assert cur[..., 3].any()
+    bad = tiles.plan_base(lv, place, 420, 300)
+    bad[1][5] = 420                                             # a footprint that leaves the raster must be refused
+    with pytest.raises(native.S2srError):
+        eng.tiles_base_u8(rgba, *bad)
+
+
+def test_process_raster_to_tiles_end_to_end(tmp_path):
+    import app.tiling as tiling
+    rgb = _scene(240, 320, seed=5)
+    georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                         rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+    src = tmp_path / "aoi_wow_sr.tif"
+    rio.write_geotiff_rgb(src, rgb, georef)
+    info = tiling.get_raster_info(src)
+    assert (info.crs, info.width, info.height, info.bands, info.dtype) == ("EPSG:32633", 320, 240, 3, "Byte")
+    cx, cy = np.array([600000.0, 600800.0, 600000.0, 600800.0]), np.array([5100000.0, 5100000.0, 5099400.0, 5099400.0])
+    lon, lat = geo.CRS(32633).to_lonlat(cx, cy)                 # grid convergence: the extremes sit at different corners
+    assert np.allclose(info.bounds_4326, [lon.min(), lat.min(), lon.max(), lat.max()], atol=1e-6)
+    meta = tiling.process_raster_to_tiles(src, tmp_path / "tiles", min_zoom=12, max_zoom=16)
+    assert meta == json.loads((tmp_path / "tiles" / "tileset.json").read_text())
+    assert meta["minzoom"] == 12 and meta["maxzoom"] == 16 and meta["tileSize"] == 256 and meta["format"] == "png"
+    assert (tmp_path / "aoi_wow_sr_3857.tif").exists()
+    for z in range(12, 17):
+        pngs = list((tmp_path / "tiles" / str(z)).glob("*/*.png"))
+        assert pngs, z
+        t = np.asarray(Image.open(pngs[0]))
+        assert t.shape == (256, 256, 4) and t[..., 3].any()
+    # the tile that holds the raster's north-west corner at z16, pixel by pixel against the oracle
+    w3857 = tiling.get_raster_info(tmp_path / "aoi_wow_sr_3857.tif")
+    assert w3857.crs == "EPSG:3857"
+    arr, georef3857 = rio.read_rgb_u8(tmp_path / "aoi_wow_sr_3857.tif")
+    place = geo.placement_from_tags(georef3857.tags)
+    plan = tiles.plan_warp(320, 240, geo.Placement(600000.0, 5100000.0, 2.5, 2.5), geo.CRS(32633))
+    alpha = ref.warp_bilinear(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)[..., 3]
+    rgba = np.dstack([arr, alpha])
+    tx, ty = geo.meters_to_tile(place.x0 + 200.0, place.y0 - 200.0, 16)
+    want = ref.base_tile(rgba, place.x0, place.y0, place.dx, place.dy, tx, ty, 16)
+    got = np.asarray(Image.open(tmp_path / "tiles" / "16" / str(tx) / f"{geo.xyz_row(ty, 16)}.png"))
+    assert np.array_equal(got, want)
+    # a raster that is already EPSG:3857 is tiled as is; anything else must be reprojected first
+    with pytest.raises(ValueError, match="EPSG:32633"):
+        tiling.generate_xyz_tiles(src, tmp_path / "nope")
+    tiling.generate_xyz_tiles(tmp_path / "aoi_wow_sr_3857.tif", tmp_path / "tiles2", min_zoom=15, max_zoom=15)
+    assert list((tmp_path / "tiles2" / "15").glob("*/*.png"))
+
+
+def test_http_wow_job_tiles_by_default(monkeypatch, tmp_path):
+    """POST /api/wow with the harness' default tiler: SR GeoTIFF (UTM, pixel size / 4) -> EPSG:3857 ->
+    z10..18 pyramid under data/tiles_wow with tileset.json, as run_wow_job does (main.py:347-359)."""
+    import torch
+    from fastapi.testclient import TestClient
+
+    from app.sr_routes import create_app
+    from s2sr.weights import synthetic_state_dict
+    monkeypatch.setenv("S2SR_MODEL_DIR", str(tmp_path / "models"))
+    (tmp_path / "models").mkdir()
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(23, seed=0).items()}
+    torch.save({"params_ema": sd}, tmp_path / "models" / "realesrgan_x4.pth")
+    rgb = _scene(24, 32, seed=8)
+    georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                         rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+    (tmp_path / "data" / "source").mkdir(parents=True)
+    rio.write_geotiff_rgb(tmp_path / "data" / "source" / "s2.tif", rgb, georef)
+    c = TestClient(create_app(tmp_path / "data"))
+    r = c.post("/api/wow", json={"auto_fetch": False})
+    st = c.get(f"/api/sr/{r.json()['job_id']}").json()
+    assert st["status"] == "completed", st
+    tdir = tmp_path / "data" / "tiles_wow"
+    assert st["result"]["tiles_dir"] == str(tdir)
+    meta = json.loads((tdir / "tileset.json").read_text())
+    assert (meta["minzoom"], meta["maxzoom"]) == (10, 18)
+    for z in (10, 14, 18):
+        pngs = list((tdir / str(z)).glob("*/*.png"))
+        assert pngs and np.asarray(Image.open(pngs[0])).shape == (256, 256, 4)
+    lon, lat = geo.CRS(32633).to_lonlat(600160.0, 5099880.0)       # centre of the 320 m x 240 m scene
+    assert meta["bounds"][0] < float(lon) < meta["bounds"][2] and meta["bounds"][1] < float(lat) < meta["bounds"][3]
