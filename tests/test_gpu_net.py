@@ -347,3 +347,22 @@ def test_full_size_batch_properties():
     e8.close()
     # outputs are images, not saturated garbage: every tile uses a wide range of values
     assert all(np.unique(y[i]).size > 64 for i in range(0, B, 5))
+
+
+def test_degenerate_image_sizes():
+    """1-pixel and few-pixel images (every patch is mostly outside the image, the halo is most of the
+    slab): float parity with the oracle in both arithmetic modes."""
+    nb = 1
+    sd = synthetic_state_dict(nb, seed=0)
+    tsd = ref.to_torch_sd(sd)
+    rng = np.random.default_rng(44)
+    for prec, tol in ((native.PREC_F16, TOL_F16), (native.PREC_F16_HP, TOL_HP)):
+        e = engine(nb, prec)
+        for (H, W) in [(1, 1), (1, 7), (5, 1), (2, 3), (3, 33), (33, 2)]:
+            img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+            _, of = ref.enhance(img, tsd, nb, return_float=True)
+            f = e.enhance_f32(img)
+            assert f.shape == (4 * H, 4 * W, 3)
+            assert np.abs(f - of).max() <= tol, (H, W, prec)
+            q = e.enhance_u8(img)
+            assert q.shape == (4 * H, 4 * W, 3)
