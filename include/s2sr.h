@@ -177,6 +177,8 @@ int  s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays);
  * server/app/wow_sr.py:59-79): TIFF-flavoured LZW (MSB-first 9..12-bit codes, early change).  Decodes
  * at most `cap` bytes into dst, *out_n = bytes produced. */
 int  s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+/* the encoder for one strip (writes compress="lzw" GeoTIFFs, wow_sr.py:138-151); cap >= n*3/2 + 16 is always enough */
+int  s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
 
 /* test hook (host only, no GPU): the OCP e4m3fn encoder the weight packer uses for the fp8
  * correction stages -- round to nearest even, saturating at +-448, NaN -> 0x7f. */

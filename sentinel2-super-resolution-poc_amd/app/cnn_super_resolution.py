@@ -107,11 +107,17 @@ class RRDBNet(nn.Module):
             h.update(str(float(t.double().sum())).encode())
         return h.hexdigest()
 
+    def _version(self):
+        """Cheap change detector: torch bumps a tensor's _version on every in-place write."""
+        return tuple((id(p), p._version) for p in self.parameters())
+
     def engine(self, device_index: int = 0) -> native.Engine:
-        key = (self._fingerprint(), device_index)
-        if self._engine is None or self._engine_key != key:
-            self._engine = _engine_for(self.state_dict(), self.num_block, device_index, key[0])
-            self._engine_key = key
+        ver = self._version()
+        if self._engine is not None and self._engine_key is not None and self._engine_key[1:] == (device_index, ver):
+            return self._engine
+        fp = self._fingerprint()
+        self._engine = _engine_for(self.state_dict(), self.num_block, device_index, fp)
+        self._engine_key = (fp, device_index, ver)
         return self._engine
 
     @torch.no_grad()
@@ -125,6 +131,8 @@ class RRDBNet(nn.Module):
 
 _ENGINES: Dict[Tuple[str, int], native.Engine] = {}
 _ENGINES_LOCK = threading.Lock()
+_LOADED_MODELS: Dict[tuple, "RRDBNet"] = {}      # checkpoint file identity -> loaded parameter shell
+_MODELS_LOCK = threading.Lock()
 
 
 def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str) -> native.Engine:
@@ -170,14 +178,31 @@ class RealESRGAN:
         self.scale = config["scale"]
         self.model_name = model_name
 
-        self.model = RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=config["channels"],
-                             num_block=config["blocks"], num_grow_ch=32, scale=self.scale)
+        # The reference builds the net and reads the 64 MB checkpoint in every job
+        # (wow_sr.py:93-97, :164-215).  Here a checkpoint file that has not changed on disk
+        # (path, mtime, size) hands back the already loaded parameter shell and its engine.
+        cache_key = None
         if state_dict is None:
-            weights_path = download_weights(model_name)
-            state_dict = select_params(torch.load(weights_path, map_location="cpu"))
-        state_dict = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
-        self.model.load_state_dict(state_dict, strict=True)
-        self.model.eval()
+            weights_path = Path(download_weights(model_name))
+            st = weights_path.stat()
+            cache_key = (str(weights_path.resolve()), st.st_mtime_ns, st.st_size, config["blocks"])
+            with _MODELS_LOCK:
+                self.model = _LOADED_MODELS.get(cache_key)
+        else:
+            self.model = None
+        if self.model is None:
+            self.model = RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=config["channels"],
+                                 num_block=config["blocks"], num_grow_ch=32, scale=self.scale)
+            if state_dict is None:
+                state_dict = select_params(torch.load(weights_path, map_location="cpu"))
+            state_dict = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()}
+            self.model.load_state_dict(state_dict, strict=True)
+            self.model.eval()
+            if cache_key is not None:
+                with _MODELS_LOCK:
+                    if len(_LOADED_MODELS) >= 8:
+                        _LOADED_MODELS.clear()
+                    _LOADED_MODELS[cache_key] = self.model
         self._engine = self.model.engine(self.device.index or 0)
         print(f"   Loaded {model_name} (x{self.scale})")
 

@@ -65,3 +65,71 @@ extern "C" int s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, 
     *out_n = pos;
     return S2SR_OK;
 }
+
+// TIFF LZW encoder (the counterpart of the decoder above; reference writes compress="lzw" GeoTIFFs,
+// server/app/wow_sr.py:138-151).  One strip per call, so strips compress in parallel on host threads.
+// Worst case output is ~1.4x the input (12-bit codes for single bytes) + a few bytes: the caller
+// sizes dst as n*3/2 + 16.
+extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
+    if (!src || !dst || !out_n) return S2SR_E_INVALID;
+    static const int HBITS = 14, HSIZE = 1 << HBITS;   // 4x the 4096 codes; entries carry a generation stamp
+    uint32_t hkey[HSIZE];                                // so a ClearCode does not cost a table wipe
+    uint16_t hval[HSIZE];
+    uint32_t gen = 1;
+    size_t pos = 0;
+    uint64_t acc = 0;
+    int nacc = 0;
+    auto put = [&](int code, int width) -> bool {
+        acc = (acc << width) | (uint32_t)code;
+        nacc += width;
+        while (nacc >= 8) {
+            if (pos >= cap) return false;
+            dst[pos++] = (uint8_t)(acc >> (nacc - 8));
+            nacc -= 8;
+        }
+        return true;
+    };
+    memset(hkey, 0, sizeof hkey);
+    auto reset = [&]() {
+        if (++gen == (1u << 12)) { memset(hkey, 0, sizeof hkey); gen = 1; }
+    };
+    int next = 258, width = 9;
+    if (!put(256, width)) return S2SR_E_CAPACITY;
+    if (n == 0) {
+        if (!put(257, width)) return S2SR_E_CAPACITY;
+    } else {
+        int prefix = src[0];
+        for (size_t i = 1; i < n; ++i) {
+            const int k = src[i];
+            const uint32_t key = (gen << 20) | ((uint32_t)prefix << 8) | (uint32_t)k;   // 12 + 12 + 8 bits
+            uint32_t h = ((((uint32_t)prefix << 8) | (uint32_t)k) * 2654435761u) >> (32 - HBITS);
+            bool found = false;
+            while ((hkey[h] >> 20) == gen) {
+                if (hkey[h] == key) { found = true; break; }
+                h = (h + 1) & (HSIZE - 1);
+            }
+            if (found) { prefix = hval[h]; continue; }
+            if (!put(prefix, width)) return S2SR_E_CAPACITY;
+            hkey[h] = key; hval[h] = (uint16_t)next++;
+            if (next == 4094) {                       // table full: ClearCode at the current width, start over
+                if (!put(256, width)) return S2SR_E_CAPACITY;
+                reset();
+                next = 258; width = 9;
+            } else if (next > (1 << width) - 1) {
+                ++width;
+            }
+            prefix = k;
+        }
+        if (!put(prefix, width)) return S2SR_E_CAPACITY;
+        ++next;                                       // the decoder adds an entry after this code too
+        if (next == 4094) { if (!put(256, width)) return S2SR_E_CAPACITY; width = 9; }
+        else if (next > (1 << width) - 1) ++width;
+        if (!put(257, width)) return S2SR_E_CAPACITY;
+    }
+    if (nacc > 0) {
+        if (pos >= cap) return S2SR_E_CAPACITY;
+        dst[pos++] = (uint8_t)(acc << (8 - nacc));
+    }
+    *out_n = pos;
+    return S2SR_OK;
+}

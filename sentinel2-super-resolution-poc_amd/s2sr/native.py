@@ -86,6 +86,7 @@ _PROTOS = {
                                         C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_base_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_overview_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "s2sr_tiff_lzw_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
@@ -116,6 +117,19 @@ def load_library():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def tiff_lzw_encode(data) -> bytes:
+    """Host call (no GPU): raw strip bytes -> TIFF LZW.  ctypes drops the GIL: strips encode in parallel."""
+    lib = load_library()
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8).ravel()
+    cap = buf.size * 3 // 2 + 16
+    out = np.empty(cap, np.uint8)
+    n = C.c_size_t(0)
+    rc = lib.s2sr_tiff_lzw_encode(buf.ctypes.data_as(C.c_void_p), buf.size, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_tiff_lzw_encode: {_ERR.get(rc, rc)}")
+    return out[:n.value].tobytes()
 
 
 def tiff_lzw_decode(data: bytes, expected: int) -> bytes:

@@ -109,22 +109,135 @@ def read_rgb_u8(path: Path, minmax_eps: float = 0.0) -> Tuple[np.ndarray, Option
     return np.ascontiguousarray(_to_u8(arr, minmax_eps)), georef
 
 
+_ADLER = 65521
+
+
+def _adler32_combine(a1: int, a2: int, len2: int) -> int:
+    """adler32(A + B) from adler32(A), adler32(B), len(B) (zlib's adler32_combine)."""
+    rem = len2 % _ADLER
+    s1, s2 = a1 & 0xFFFF, (rem * (a1 & 0xFFFF)) % _ADLER
+    s1 += (a2 & 0xFFFF) + _ADLER - 1
+    s2 += ((a1 >> 16) & 0xFFFF) + ((a2 >> 16) & 0xFFFF) + _ADLER - rem
+    if s1 >= _ADLER:
+        s1 -= _ADLER
+    if s1 >= _ADLER:
+        s1 -= _ADLER
+    if s2 >= 2 * _ADLER:
+        s2 -= 2 * _ADLER
+    if s2 >= _ADLER:
+        s2 -= _ADLER
+    return (s2 << 16) | s1
+
+
+def encode_png(img: np.ndarray, level: int = 3, band_rows: int = 128, workers: Optional[int] = None) -> bytes:
+    """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> PNG bytes.  The SR outputs are tens of megapixels and PNG
+    deflate is what a job spends most of its time in, so the image is cut into bands that are filtered
+    (Sub) and deflated on a thread pool (zlib releases the GIL), each band ending on a sync flush so
+    that the pieces concatenate into one valid zlib stream (the pigz construction)."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    img = np.ascontiguousarray(img)
+    h, w, c = img.shape
+    if img.dtype != np.uint8 or c not in (3, 4):
+        raise ValueError(f"expected HxWx3 or HxWx4 uint8, got {img.shape} {img.dtype}")
+    rows = img.reshape(h, w * c)
+    bands = [(y, min(h, y + band_rows)) for y in range(0, h, band_rows)]
+
+    def work(i):
+        y0, y1 = bands[i]
+        blk = rows[y0:y1]
+        raw = np.empty((y1 - y0, w * c + 1), np.uint8)
+        raw[:, 0] = 1                                              # filter type Sub
+        raw[:, 1:c + 1] = blk[:, :c]
+        raw[:, c + 1:] = blk[:, c:] - blk[:, :-c]
+        data = raw.tobytes()
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        out = co.compress(data) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        return out, zlib.adler32(data), len(data)
+
+    n = workers or min(16, os.cpu_count() or 4)
+    if len(bands) > 1 and n > 1:
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            parts = list(pool.map(work, range(len(bands))))
+    else:
+        parts = [work(i) for i in range(len(bands))]
+    adler = 1
+    for _, a, ln in parts:
+        adler = _adler32_combine(adler, a, ln)
+    idat = b"\x78\x5e" + b"".join(p for p, _, _ in parts) + struct.pack(">I", adler)
+
+    def chunk(kind: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+
+    # IDAT payloads are capped at 2^31-1 bytes: split (a 16k x 16k RGB image stays far below)
+    idats = b"".join(chunk(b"IDAT", idat[i:i + (1 << 30)]) for i in range(0, len(idat), 1 << 30))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)) +
+            idats + chunk(b"IEND", b""))
+
+
 def write_png(path: Path, rgb: np.ndarray) -> None:
-    Image.fromarray(np.ascontiguousarray(rgb), "RGB").save(str(path), format="PNG", compress_level=3)
+    Path(path).write_bytes(encode_png(rgb))
 
 
-def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef) -> None:
-    """uint8 RGB, LZW compressed (compress="lzw", wow_sr.py:138-151) with the geo tags."""
-    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_strip: int = 64) -> None:
+    """uint8 RGB, LZW compressed (compress="lzw", wow_sr.py:138-151) with the geo tags.  Classic
+    little-endian TIFF, chunky RGB strips; the strips are LZW-encoded by the native library on a
+    thread pool (the SR outputs are tens of megapixels; a single-threaded encoder is what a job would
+    otherwise wait for)."""
+    import os
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import native
+
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, c = rgb.shape
+    if c != 3:
+        raise ValueError(f"expected HxWx3, got {rgb.shape}")
+    strips = [(y, min(h, y + rows_per_strip)) for y in range(0, h, rows_per_strip)]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+        enc = list(pool.map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips))
+    offs, pos = [], 8
+    for e in enc:
+        offs.append(pos)
+        pos += len(e) + (len(e) & 1)
+    if pos >= (1 << 32) - (1 << 20):
+        raise ValueError("output exceeds the 4 GiB of a classic TIFF")
+    ent = [(256, 4, (w,)), (257, 4, (h,)), (258, 3, (8, 8, 8)), (259, 3, (5,)), (262, 3, (2,)), (273, 4, tuple(offs)),
+           (277, 3, (3,)), (278, 4, (rows_per_strip,)), (279, 4, tuple(len(e) for e in enc)), (284, 3, (1,)), (339, 3, (1, 1, 1))]
     for tag, val in georef.tags.items():
         if tag == TAG_GEOKEYS:
-            ifd[tag] = tuple(int(v) for v in val)
-            ifd.tagtype[tag] = TiffTags.SHORT
+            ent.append((tag, 3, tuple(int(v) for v in val)))
         elif tag == TAG_GEOASCII:
-            ifd[tag] = val if isinstance(val, str) else str(val)
-            ifd.tagtype[tag] = TiffTags.ASCII
+            ent.append((tag, 2, val if isinstance(val, str) else str(val)))
         else:
-            ifd[tag] = tuple(float(v) for v in val)
-            ifd.tagtype[tag] = TiffTags.DOUBLE
-    Image.fromarray(np.ascontiguousarray(rgb), "RGB").save(str(path), format="TIFF", compression="tiff_lzw",
-                                                           tiffinfo=ifd)
+            ent.append((tag, 12, tuple(float(v) for v in val)))
+    ent.sort(key=lambda e: e[0])
+    fmt = {3: "H", 4: "I", 12: "d"}
+    ifd_off = pos
+    val_pos = ifd_off + 2 + 12 * len(ent) + 4
+    ifd, tail = b"", b""
+    for tag, typ, vals in ent:
+        if typ == 2:
+            data = vals.encode("latin-1") + b"\0"
+            cnt = len(data)
+        else:
+            data = struct.pack("<" + fmt[typ] * len(vals), *vals)
+            cnt = len(vals)
+        e = struct.pack("<HHI", tag, typ, cnt)
+        if len(data) <= 4:
+            e += data.ljust(4, b"\0")
+        else:
+            e += struct.pack("<I", val_pos + len(tail))
+            tail += data + (b"\0" if len(data) & 1 else b"")
+        ifd += e
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_off))
+        for e in enc:
+            f.write(e)
+            if len(e) & 1:
+                f.write(b"\0")
+        f.write(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)

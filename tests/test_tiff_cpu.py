@@ -163,3 +163,48 @@ def test_read_rgb_u8_on_sentinel_like_geotiff(tmp_path):
     back, g2 = rio.read_rgb_u8(out)
     assert back.shape == (360, 480, 3) and g2.pixel_size == (2.5, 2.5)
     assert tuple(g2.tags[33922]) == (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0)
+
+
+def test_lzw_encoder_roundtrip_and_libtiff_reads_it(tmp_path):
+    """Native LZW encoder: decodes back through the native decoder, and libtiff (via PIL) reads the
+    GeoTIFFs written with it -- pixels and geo tags -- for sizes around the strip height."""
+    from s2sr import native
+    rng = np.random.default_rng(2)
+    for data in (b"", b"a", b"ab" * 5000, bytes(range(256)) * 64, rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(),
+                 rng.integers(0, 3, 200000, dtype=np.uint8).tobytes()):
+        enc = native.tiff_lzw_encode(data)
+        assert native.tiff_lzw_decode(enc, len(data)) == data
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                      rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633),
+                      rio.TAG_GEOASCII: "WGS 84 / UTM zone 33N|"})
+    for shape in ((1, 1, 3), (63, 5, 3), (64, 64, 3), (65, 7, 3), (300, 411, 3)):
+        a = _scene(shape[0], shape[1], 3, np.uint8, seed=shape[0])
+        p = tmp_path / "o.tif"
+        rio.write_geotiff_rgb(p, a, geo)
+        im = Image.open(p)
+        assert np.array_equal(np.asarray(im), a), shape
+        tv = im.tag_v2
+        assert tv[259] == 5 and tuple(tv[33550]) == (2.5, 2.5, 0.0) and tuple(tv[34735])[-1] == 32633
+        assert tv[34737].startswith("WGS 84 / UTM zone 33N")
+        back, g2 = rio.read_rgb_u8(p)
+        assert np.array_equal(back, a) and g2.pixel_size == (2.5, 2.5)
+
+
+def test_png_encoder_bands_form_one_stream():
+    """Parallel PNG encoder: bands deflated independently and stitched with sync flushes + a combined
+    Adler-32 must decode (PIL / zlib) to the input, for RGB and RGBA, with and without threads."""
+    import io
+    import zlib
+    rng = np.random.default_rng(3)
+    data = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (1, 70000, 5, 300001)]
+    ad = 1
+    for d in data:
+        ad = rio._adler32_combine(ad, zlib.adler32(d), len(d))
+    assert ad == zlib.adler32(b"".join(data))
+    for shape in ((1, 1, 3), (5, 7, 4), (129, 64, 3), (300, 401, 3), (513, 100, 4)):
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        for workers in (1, 4):
+            im = Image.open(io.BytesIO(rio.encode_png(a, band_rows=128, workers=workers)))
+            assert im.mode == ("RGB" if shape[2] == 3 else "RGBA") and np.array_equal(np.asarray(im), a), (shape, workers)
+    with pytest.raises(ValueError):
+        rio.encode_png(np.zeros((4, 4, 2), np.uint8))

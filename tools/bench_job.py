@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Where a /api/wow job spends its time (process_wow_sr on a 1024x1024 GeoTIFF -> 4096x4096 outputs)."""
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from s2sr import rasterio_lite as rio  # noqa: E402
+from s2sr.weights import synthetic_state_dict  # noqa: E402
+
+side = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+tmp = Path(tempfile.mkdtemp())
+import os  # noqa: E402
+os.environ["S2SR_MODEL_DIR"] = str(tmp / "models")
+(tmp / "models").mkdir()
+sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(23, seed=0).items()}
+torch.save({"params_ema": sd}, tmp / "models" / "realesrgan_x4.pth")
+yy, xx = np.mgrid[0:side, 0:side]
+rng = np.random.default_rng(0)
+rgb = np.stack([110 + 70 * np.sin(xx / 23.0 + c) * np.cos(yy / 17.0) + rng.integers(-12, 13, (side, side)) for c in range(3)], -1)
+rgb = np.clip(rgb, 0, 255).astype(np.uint8)
+georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                     rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+rio.write_geotiff_rgb(tmp / "aoi.tif", rgb, georef)
+
+from app.wow_sr import process_wow_sr  # noqa: E402
+import app.wow_sr as w  # noqa: E402
+
+process_wow_sr(tmp / "aoi.tif", tmp / "warm")          # weights, engine, graphs
+stages = {}
+orig = {"read": rio.read_rgb_u8, "tif": rio.write_geotiff_rgb, "png": rio.write_png, "pp": w._enhance_for_crops}
+
+
+def timed(name, fn):
+    def f(*a, **k):
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    return f
+
+
+rio.read_rgb_u8 = timed("read GeoTIFF", orig["read"])
+rio.write_geotiff_rgb = timed("write GeoTIFF (LZW)", orig["tif"])
+rio.write_png = timed("write PNG", orig["png"])
+w._enhance_for_crops = timed("post-process (GPU, host in/out)", orig["pp"])
+real_enh = w.RealESRGAN.enhance
+w.RealESRGAN.enhance = timed("SR net (GPU, host in/out)", real_enh)
+t0 = time.perf_counter()
+process_wow_sr(tmp / "aoi.tif", tmp / "run")
+total = time.perf_counter() - t0
+print(f"process_wow_sr {side}x{side} -> {4*side}x{4*side}: {total*1e3:.0f} ms")
+for k, v in stages.items():
+    print(f"  {k:36s} {v*1e3:8.1f} ms")
+print(f"  {'other (BGR flips, json, ...)':36s} {(total - sum(stages.values()))*1e3:8.1f} ms")
