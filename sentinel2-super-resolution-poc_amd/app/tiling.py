@@ -121,22 +121,14 @@ def reproject_to_web_mercator(input_path: Path, output_path: Path, resample_meth
     return output_path
 
 
-def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, max_zoom: int = 16, tile_size: int = 256,
-                       resampling: str = "average", alpha: Optional[np.ndarray] = None) -> Path:
-    """z/x/y.png (XYZ row order, RGBA) for every tile of zooms min..max that holds data."""
-    if tile_size != 256 or resampling != "average":
-        raise ValueError("tile_size 256 and average resampling are what the reference uses and what is implemented")
-    input_path, output_dir = Path(input_path), Path(output_dir)
-    arr, _tags, place, crs = _read(input_path)
-    if crs.epsg != 3857:
-        raise ValueError(f"{input_path}: {crs}, tiles are cut from an EPSG:3857 raster (reproject_to_web_mercator first)")
-    h, w = arr.shape[:2]
-    rgba = np.empty((h, w, 4), np.uint8)
-    rgba[..., :3] = arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2)
-    rgba[..., 3] = 255 if alpha is None else alpha
+def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_zoom: int, max_zoom: int) -> None:
+    """RGBA raster on the EPSG:3857 grid -> z/x/y.png files (deepest zoom from the raster, the others
+    from their children); PNG encoding overlaps the next level's kernels on a thread pool."""
+    h, w = rgba.shape[:2]
     output_dir.mkdir(parents=True, exist_ok=True)
     eng = _engine()
     levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
+
     def write_tile(args):
         t, path = args
         path.write_bytes(encode_png_rgba(t))
@@ -151,16 +143,31 @@ def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, m
                 ox, oy = tiles.overview_offsets(lv, prev_lv)
                 cur = eng.tiles_overview_u8(prev, ox, oy, lv.nx, lv.ny)
             has_data = cur[..., 3].reshape(lv.ny, lv.nx, -1).any(-1)
-            jobs = []
             for i in range(lv.nx):
                 if has_data[:, i].any():
                     (output_dir / str(lv.zoom) / str(lv.tminx + i)).mkdir(parents=True, exist_ok=True)
-            for j, i in zip(*np.nonzero(has_data)):
-                jobs.append((cur[j, i], output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png"))
+            jobs = [(cur[j, i], output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png")
+                    for j, i in zip(*np.nonzero(has_data))]
             pending.append(pool.map(write_tile, jobs, chunksize=8))     # encoded while the next level is computed
             prev, prev_lv = cur, lv
         for p in pending:
             list(p)                                                     # surface any exception
+
+
+def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, max_zoom: int = 16, tile_size: int = 256,
+                       resampling: str = "average") -> Path:
+    """z/x/y.png (XYZ row order, RGBA) for every tile of zooms min..max that holds data."""
+    if tile_size != 256 or resampling != "average":
+        raise ValueError("tile_size 256 and average resampling are what the reference uses and what is implemented")
+    input_path, output_dir = Path(input_path), Path(output_dir)
+    arr, _tags, place, crs = _read(input_path)
+    if crs.epsg != 3857:
+        raise ValueError(f"{input_path}: {crs}, tiles are cut from an EPSG:3857 raster (reproject_to_web_mercator first)")
+    h, w = arr.shape[:2]
+    rgba = np.empty((h, w, 4), np.uint8)
+    rgba[..., :3] = arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2)
+    rgba[..., 3] = 255
+    _cut_pyramid(rgba, place, output_dir, min_zoom, max_zoom)
     logger.info("Tile generation complete: %s", output_dir)
     return output_dir
 
@@ -178,17 +185,24 @@ def create_tileset_metadata(tiles_dir: Path, bounds_4326: list, min_zoom: int, m
 def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 10, max_zoom: int = 16) -> dict:
     """Check the CRS, reproject if needed, cut the pyramid, write tileset.json."""
     input_path, tiles_dir = Path(input_path), Path(tiles_dir)
-    info = get_raster_info(input_path)
-    alpha = None
-    if info.crs != "EPSG:3857":
-        working = input_path.parent / f"{input_path.stem}_3857.tif"
-        arr, _tags, place, crs = _read(input_path)
-        rgb = rio._to_u8(arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
-        plan = tiles.plan_warp(rgb.shape[1], rgb.shape[0], place, crs)
-        out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
-        rio.write_geotiff_rgb(working, np.ascontiguousarray(out[..., :3]), _mercator_tags(plan.placement))
-        alpha = out[..., 3]
+    arr, _tags, place, crs = _read(input_path)
+    h, w, b = arr.shape
+    west, south, east, north = place.bounds(w, h)
+    t = np.linspace(0.0, 1.0, 21)
+    ex = np.concatenate([west + (east - west) * t, np.full(21, east), east - (east - west) * t, np.full(21, west)])
+    ey = np.concatenate([np.full(21, north), north - (north - south) * t, np.full(21, south), south + (north - south) * t])
+    lon, lat = crs.to_lonlat(ex, ey)
+    bounds_4326 = [float(lon.min()), float(lat.min()), float(lon.max()), float(lat.max())]
+    rgb = rio._to_u8(arr[..., :3] if b >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
+    if crs.epsg != 3857:
+        # the warped raster is written next to the input like the reference does (<stem>_3857.tif, :251-252),
+        # but the pyramid is cut from the array in hand, with the coverage mask of the warp as alpha
+        plan = tiles.plan_warp(w, h, place, crs)
+        rgba = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+        rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
+                              _mercator_tags(plan.placement))
+        place = plan.placement
     else:
-        working = input_path
-    generate_xyz_tiles(working, tiles_dir, min_zoom=min_zoom, max_zoom=max_zoom, alpha=alpha)
-    return create_tileset_metadata(tiles_dir, info.bounds_4326, min_zoom, max_zoom)
+        rgba = np.dstack([rgb, np.full((h, w), 255, np.uint8)])
+    _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom)
+    return create_tileset_metadata(tiles_dir, bounds_4326, min_zoom, max_zoom)

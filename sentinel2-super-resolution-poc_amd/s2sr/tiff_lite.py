@@ -151,24 +151,33 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
     if len(offs) < nx * ny * planes:
         raise TiffError(f"{path}: {len(offs)} chunks listed, {nx * ny * planes} needed")
     out = np.zeros((H, W, spp), dtype=dt.newbyteorder("="))
-    k = 0
-    for pl in range(planes):
-        for iy in range(ny):
-            for ix in range(nx):
-                o, c = int(offs[k]), int(cnts[k])
-                k += 1
-                rows = ch if tiled else min(ch, H - iy * ch)    # strips are not padded, tiles are
-                expected = rows * cw * cspp * dt.itemsize
-                data = _decompress(comp, bytes(buf[o:o + c]), expected)
-                if len(data) < expected:
-                    raise TiffError(f"{path}: chunk {k - 1} decodes to {len(data)} bytes, {expected} expected")
-                a = np.frombuffer(data, dtype=dt, count=rows * cw * cspp).reshape(rows, cw, cspp)
-                if pred == 2:     # horizontal differencing, per sample, modulo the sample width
-                    a = np.cumsum(a.astype(dt.newbyteorder("=")), axis=1, dtype=dt.newbyteorder("="))
-                y0, x0 = iy * ch, ix * cw
-                h, w = min(rows, H - y0), min(cw, W - x0)
-                if planar == 2:
-                    out[y0:y0 + h, x0:x0 + w, pl] = a[:h, :w, 0]
-                else:
-                    out[y0:y0 + h, x0:x0 + w, :] = a[:h, :w, :]
+
+    def chunk(k: int) -> None:          # chunks are independent: decoded on a thread pool (zlib and the
+        pl, rem = divmod(k, nx * ny)    # native LZW decoder both run without the GIL)
+        iy, ix = divmod(rem, nx)
+        o, c = int(offs[k]), int(cnts[k])
+        rows = ch if tiled else min(ch, H - iy * ch)    # strips are not padded, tiles are
+        expected = rows * cw * cspp * dt.itemsize
+        data = _decompress(comp, bytes(buf[o:o + c]), expected)
+        if len(data) < expected:
+            raise TiffError(f"{path}: chunk {k} decodes to {len(data)} bytes, {expected} expected")
+        a = np.frombuffer(data, dtype=dt, count=rows * cw * cspp).reshape(rows, cw, cspp)
+        if pred == 2:     # horizontal differencing, per sample, modulo the sample width
+            a = np.cumsum(a.astype(dt.newbyteorder("=")), axis=1, dtype=dt.newbyteorder("="))
+        y0, x0 = iy * ch, ix * cw
+        h, w = min(rows, H - y0), min(cw, W - x0)
+        if planar == 2:
+            out[y0:y0 + h, x0:x0 + w, pl] = a[:h, :w, 0]
+        else:
+            out[y0:y0 + h, x0:x0 + w, :] = a[:h, :w, :]
+
+    nchunks = nx * ny * planes
+    if comp != 1 and nchunks > 4 and H * W * spp * dt.itemsize > (1 << 22):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+            list(pool.map(chunk, range(nchunks)))
+    else:
+        for k in range(nchunks):
+            chunk(k)
     return out, t

@@ -58,3 +58,13 @@ print(f"process_wow_sr {side}x{side} -> {4*side}x{4*side}: {total*1e3:.0f} ms")
 for k, v in stages.items():
     print(f"  {k:36s} {v*1e3:8.1f} ms")
 print(f"  {'other (BGR flips, json, ...)':36s} {(total - sum(stages.values()))*1e3:8.1f} ms")
+
+# the tiling stage that follows in run_wow_job (main.py:347-359): z10..18 pyramid of the SR GeoTIFF
+from app.tiling import process_raster_to_tiles  # noqa: E402
+sr_tif = tmp / "run" / "aoi_wow_sr.tif"
+process_raster_to_tiles(sr_tif, tmp / "tiles_warm", 10, 12)
+t0 = time.perf_counter()
+meta = process_raster_to_tiles(sr_tif, tmp / "tiles", 10, 18)
+dt = time.perf_counter() - t0
+ntiles = sum(1 for _ in (tmp / "tiles").glob("*/*/*.png"))
+print(f"process_raster_to_tiles z10..18: {ntiles} tiles in {dt*1e3:.0f} ms")
