@@ -762,16 +762,21 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
     auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8>;
     if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
+    // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs
+    static bool attr_set[64] = {false};
+    static int ncu_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return e;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        attr_set = true;
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu_dev[dev] = n;
+        attr_set[dev] = true;
     }
+    const int ncu = ncu_dev[dev];
     if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage % R != 0 || p.nstage < 4))
         return hipErrorInvalidValue;   // the trunk forms pick x out of ring slots 0..3 (see hi_cap)
     ConvParams q = p;
