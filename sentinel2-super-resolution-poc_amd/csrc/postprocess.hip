@@ -12,6 +12,7 @@
 // with -ffp-contract=off so no multiply-add is fused.
 #include <math.h>
 
+#include <mutex>
 #include <vector>
 
 #include "s2sr_internal.h"
@@ -90,6 +91,8 @@ hipError_t get_tables(PPTables** out) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    static std::mutex mu;                      // handles on different threads may get here together
+    std::lock_guard<std::mutex> lk(mu);
     if (!g_d_tables[dev]) {
         PPTables* h = new PPTables();
         build_tables(*h);
