@@ -113,3 +113,15 @@ def test_radius3_tiny_and_misaligned_batch(eng):
                                  torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().reshape(35, 203, 3), pp.enhance_for_crops(batch[0]))
+
+
+def test_full_pipelines_on_tiny_and_thin_images(eng):
+    """Images smaller than the CLAHE grid / the blur radius, 1-pixel wide or high: every stage pads by
+    reflection (more than one bounce) and must still match the oracle bit for bit."""
+    rng = np.random.default_rng(13)
+    for shape in ((1, 1, 3), (1, 9, 3), (7, 1, 3), (3, 5, 3), (8, 8, 3), (9, 17, 3), (2, 300, 3)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[..., 1] = np.maximum(img[..., 1], 90)
+        for prm, fn in ((native.pp_wow(), pp.enhance_for_crops), (native.pp_farm(), pp.farm_postprocess)):
+            got = eng.postprocess_u8(img, prm)
+            assert np.array_equal(got, fn(img)), shape
