@@ -32,6 +32,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "s2sr_internal.h"
 
 #ifndef S2SR_DMA_LATE
@@ -54,19 +56,19 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int WAVES_, int NP_, int CT_, int R_>
+template <int WAVES_, int NP_, int CT_, int R_, int TAPS_ = 9>
 struct Geom {
-    static constexpr int WAVES = WAVES_, NP = NP_, CT = CT_, R = R_;
+    static constexpr int WAVES = WAVES_, NP = NP_, CT = CT_, R = R_, TAPS = TAPS_;
     static constexpr int TH = WAVES * NP, TW = 32;
     static constexpr int SW = TW + 2, SH = TH + 2, SPX = SH * SW;
     static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
     static constexpr int PI = PLANE / 1024;            // slab LDS-DMA instructions per stage
-    static constexpr int WI = 9 * CT;                  // weight LDS-DMA instructions per stage
+    static constexpr int WI = TAPS * CT;               // weight LDS-DMA instructions per stage
     static constexpr int NSTI = PI + WI;
     static constexpr int PW = (NSTI + WAVES - 1) / WAVES;   // DMA instructions per wave per stage
     static constexpr int STAGE_BYTES = NSTI * 1024;
     static constexpr int BIAS_OFF = R * STAGE_BYTES;
-    static constexpr int LDS_BYTES = BIAS_OFF + 256;
+    static constexpr int LDS_BYTES = BIAS_OFF + (CT * 128 > 256 ? CT * 128 : 256);   // fp32 bias per cout tile
     static constexpr int NBSTEP = 3 * (NP + 2);        // B fragments read per stage
 };
 
@@ -153,10 +155,25 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // correction terms run at twice the fp16 rate on half the bytes.  An fp8 plane is 32 B per pixel,
 // byte-for-byte the geometry of an fp16 block-16 plane, so loader, ring and swizzle are shared.
 // HPO (their producers): besides the fp16 output, write those fp8 planes (p.T: lo8 p0, p1, hi8 p0, p1).
-template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false>
+// PH >= 0 (F8 kernels only): sub-pixel form of "nearest-2x upsample, then 3x3 conv" (conv_up1 / conv_up2,
+// cnn_super_resolution.py:146-154).  The two upsampled rows 2y, 2y+1 are the same source row, so the
+// output pixels of row parity py = PH are a 2x2-tap conv of the SOURCE image with the 3x3 taps that
+// land on the same source pixel summed on the host (py = 0: rows {dy 0} {dy 1,2} on source rows y-1, y;
+// py = 1: {dy 0,1} {dy 2} on y, y+1; same in x): 4 MACs per output pixel instead of 9, identical up to
+// fp32 rounding of the summed weights.  One launch does both column parities, as extra "cout tiles":
+// tile ct = q * CTR + rc holds couts rc*32.. of parity q, whose B fragments are the slab shifted by one
+// more column -- so a lane owns the output pixels 2x and 2x+1 and a wave row writes whole cache lines
+// (one parity per launch would write every other 32-B sector of each line: read-modify-write in L2/HBM).
+// The launch walks patches of the source image (p.H, p.W, sHp, sWp = source; Hp, Wp = the 2x output
+// tensor) and stores to (2y+py, 2x+q).
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false,
+          int PH = -1>
 __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
-    using G = Geom<WAVES, NP, CT, R>;
+    using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
     static_assert(!F8 || R == 4, "the fp8 pair schedule is written for a 4-slot ring");
+    static_assert(PH < 0 || (F8 && !UP && CT % 2 == 0), "the sub-pixel form is instantiated for the split-operand up-convs");
+    constexpr int PY = PH >= 0 ? PH : 0;
+    constexpr int CTR = PH >= 0 ? CT / 2 : CT;     // real cout tiles; in the sub-pixel form tile ct = q*CTR + rc, q = column parity
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -182,7 +199,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     const uint32_t sblk = (uint32_t)p.sHp * p.sWp * 32;              // bytes between source blocks
     const size_t oblk = (size_t)p.Hp * p.Wp * 32;                    // bytes between output blocks
 
-    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = (EPI == EPI_FIRST) ? 0.f : p.bias[tid];
+    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = (EPI == EPI_FIRST) ? 0.f : p.bias[tid % (CTR * 32)];
 
     // ---- per-lane source offsets of this wave's PW DMA slots (patch independent)
     uint32_t loff[G::PW];
@@ -349,7 +366,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     // ---- F8 kernels: both stage kinds walk dx -> slab row -> dy, so only the three A fragments of one
     // kernel column are live (the 9-tap residency of stage_body plus the fp8 operands would spill).
     // Every B fragment is still read once and feeds the kernel rows it belongs to.
-    constexpr int NB = NP + 2;
+    constexpr int KT = PH >= 0 ? 2 : 3;          // kernel extent per axis (sub-pixel form: 2)
+    constexpr int NBK = NP + KT - 1;             // slab rows a wave touches
     const char* sbv[2] = {nullptr, nullptr};
     const char* wbv[2] = {nullptr, nullptr};
     uint32_t slv[2] = {0, 0};
@@ -365,7 +383,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     auto dma_step = [&](int step, int n_issue) __attribute__((always_inline)) {   // `step` is a compile-time constant at every call
 #pragma unroll
         for (int sq = 0; sq < 2 * G::PW; ++sq) {
-            constexpr int LASTSTEP = 3 * NB - 1;
+            constexpr int LASTSTEP = 3 * NBK - 1;
             if ((sq < LASTSTEP ? sq : LASTSTEP) != step) continue;
             const int w = sq / G::PW, sl = sq % G::PW;
             if (w >= n_issue) continue;
@@ -385,31 +403,42 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     };
     auto stage16_dx = [&](const char* buf, int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
         plan_dma(n_issue, sl_off, sl_off1);
-        f16x8 a[2][3][CT];   // this column's fragments and the next column's, fetched a column ahead
+        // columns of the slab: 3 shifts.  Plain form: shift dx = kernel column dx for every tile.  Sub-pixel
+        // form: tile ct of column parity q uses kernel column bt = dx - q in {0, 1}.
+        f16x8 a[2][KT][CT];   // this column's fragments and the next column's, fetched a column ahead
         auto load_a = [&](int dx) __attribute__((always_inline)) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < KT; ++dy)
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) a[dx & 1][dy][ct] = *(const f16x8*)(buf + aaddr + ((dy * 3 + dx) * CT + ct) * 1024);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int bt = PH >= 0 ? dx - ct / CTR : dx;
+                    if (bt < 0 || bt >= KT) continue;
+                    a[dx & 1][dy][ct] = *(const f16x8*)(buf + aaddr + ((dy * KT + bt) * CT + ct) * 1024);
+                }
         };
-        load_a(0);
+        constexpr bool APF16 = !(PH >= 0 && NP >= 2);
+        if (APF16) load_a(0);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
+            if (!APF16) load_a(dx);
             f16x8 b[2];
-            b[0] = *(const f16x8*)(buf + baddr[0][dx]);
+            b[0] = *(const f16x8*)(buf + baddr[PY][dx]);
 #pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                if (s + 1 < NB) b[(s + 1) & 1] = *(const f16x8*)(buf + baddr[s + 1][dx]);
-                if (s == 0 && dx < 2) load_a(dx + 1);
+            for (int s = 0; s < NBK; ++s) {      // slab row s + PY
+                if (s + 1 < NBK) b[(s + 1) & 1] = *(const f16x8*)(buf + baddr[s + 1 + PY][dx]);
+                if (APF16 && s == 0 && dx + 1 < 3) load_a(dx + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                dma_step(dx * NB + s, n_issue);
+                dma_step(dx * NBK + s, n_issue);
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
+                for (int dy = 0; dy < KT; ++dy) {
                     const int np = s - dy;
                     if (np < 0 || np >= NP) continue;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int bt = PH >= 0 ? dx - ct / CTR : dx;
+                        if (bt < 0 || bt >= KT) continue;
                         acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dx & 1][dy][ct], b[s & 1], acc[ct][np], 0, 0, 0);
+                    }
                 }
             }
             pin_acc();
@@ -431,35 +460,42 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             const v4i l0 = sw ? x1 : x0, l1 = sw ? x0 : x1;
             return __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        v8i a8[2][3][CT];
+        v8i a8[2][KT][CT];
         auto load_a8 = [&](int dx) __attribute__((always_inline)) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < KT; ++dy)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const char* fp = mb + afrag + (uint32_t)((dy * 3 + dx) * CT + ct) * 1024;
+                    const int bt = PH >= 0 ? dx - ct / CTR : dx;
+                    if (bt < 0 || bt >= KT) continue;
+                    const char* fp = mb + afrag + (uint32_t)((dy * KT + bt) * CT + ct) * 1024;
                     const v4i x0 = *(const v4i*)(fp), x1 = *(const v4i*)(fp + 512);
                     a8[dx & 1][dy][ct] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
         };
-        load_a8(0);
+        constexpr bool APF = !(PH >= 0 && NP >= 2);   // fetch the next column's A fragments a column ahead (register budget permitting)
+        if (APF) load_a8(0);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
+            if (!APF) load_a8(dx);
             v8i b8[2];
-            b8[0] = bfrag(0, dx);
+            b8[0] = bfrag(PY, dx);
 #pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                if (s + 1 < NB) b8[(s + 1) & 1] = bfrag(s + 1, dx);
-                if (s == 1 && dx < 2) load_a8(dx + 1);
+            for (int s = 0; s < NBK; ++s) {
+                if (s + 1 < NBK) b8[(s + 1) & 1] = bfrag(s + 1 + PY, dx);
+                if (APF && s == (NBK > 2 ? 1 : 0) && dx + 1 < 3) load_a8(dx + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                dma_step(dx * NB + s, n_issue);
+                dma_step(dx * NBK + s, n_issue);
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
+                for (int dy = 0; dy < KT; ++dy) {
                     const int np = s - dy;
                     if (np < 0 || np >= NP) continue;
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)   // e4m3 x e4m3, scale_a = 2^0, scale_b = 2^-11 (E8M0 bytes 127, 116)
+                    for (int ct = 0; ct < CT; ++ct) {   // e4m3 x e4m3, scale_a = 2^0, scale_b = 2^-11 (E8M0 bytes 127, 116)
+                        const int bt = PH >= 0 ? dx - ct / CTR : dx;
+                        if (bt < 0 || bt >= KT) continue;
                         acc[ct][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[dx & 1][dy][ct], b8[s & 1], acc[ct][np], 0, 0, 0, 127, 0, 116);
+                    }
                 }
             }
             pin_acc();
@@ -480,7 +516,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
             ok[np] = (y < p.H) && (x < p.W);
-            opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
+            opix[np] = PH >= 0 ? (size_t)(2 * y + PY + 1) * p.Wp + (2 * x + 1)    // sub-pixel form: row parity PY, column parity q added per tile
+                               : (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t tn = (size_t)n * 8 * oblk;   // image offset inside an fp32 skip tensor (R, F), bytes
         const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensor, bytes
@@ -524,6 +561,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
+                const int rc = ct % CTR;                                   // real cout tile
+                const size_t qoff = PH >= 0 ? (size_t)(ct / CTR) * 32 : 0;   // sub-pixel form: the pixel to the right
                 u32x2 hpk[4];   // fp16 x4 per g (hi / plain output)
                 u32x2 lpk[4];   // fp16 x4 per g (lo), trunk forms and conv_first
                 uint32_t lo8[4], hi8[4];   // e4m3 x4 per g (HPO): channels 8g+4hh .. +3 of fp8 plane ct
@@ -611,7 +650,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
                         u32x4 o;
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
-                        *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
+                        *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(rc * 2 + bk) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
                         if (kTrunk || EPI == EPI_FIRST) {
                             u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
                             const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
@@ -631,7 +670,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             const auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                             u32x4 o;
                             o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
-                            *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(2 * w + ct) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
+                            *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(2 * w + rc) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
                         }
                     }
                 }
@@ -755,12 +794,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false>
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false,
+          int PH = -1>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
-    using G = Geom<WAVES, NP, CT, R>;
+    using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
     static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
-    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8>;
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH>;
     if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
     // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs
     static bool attr_set[64] = {false};
@@ -826,6 +866,14 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
         if (epi == EPI_BODY && !up) return launch_w<2, EPI_BODY, false>(p, st);
         if (epi == EPI_DEBUG) return up ? launch_w<2, EPI_DEBUG, true>(p, st) : launch_w<2, EPI_DEBUG, false>(p, st);
     }
+    return hipErrorInvalidValue;
+}
+
+// one ROW parity of a split-operand up-conv in sub-pixel form (both column parities inside the launch;
+// p.H, p.W = source dims, p.Hp, p.Wp = 2x tensor)
+hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st) {
+    if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 0>(p, st);
+    if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 1>(p, st);
     return hipErrorInvalidValue;
 }
 
@@ -904,13 +952,22 @@ uint8_t f32_to_e4m3(float f) {
     return sign | (uint8_t)(((E + 7) << 3) | (q - 8));
 }
 
-void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host) {
-    const int CT = (cout + 31) / 32;
-    pack_conv_weights(w, cin, cout, 1, dst_host);                       // stages 0..3: fp16 w_hi
-    uint8_t* d = (uint8_t*)dst_host + conv_wpack_bytes_seg(cin, cout, 1);
+// w: [cout][cin][taps] fp32 (taps = 9: OIHW 3x3; taps = 4: the 2x2 sub-pixel kernels below)
+static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* dst_host) {
+    const int CT = (cout + 31) / 32, ns = (cin + 15) / 16;
+    f16* d16 = (f16*)dst_host;                                          // stages 0..ns-1: fp16 w_hi, [s][t][ct][lane][8]
+    for (int s = 0; s < ns; ++s)
+        for (int t = 0; t < taps; ++t)
+            for (int ct = 0; ct < CT; ++ct)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = ct * 32 + (l & 31), ci = s * 16 + 8 * (l >> 5) + j;
+                        *d16++ = (co < cout && ci < cin) ? (f16)w[((size_t)co * cin + ci) * taps + t] : (f16)0.f;
+                    }
+    uint8_t* d = (uint8_t*)d16;
     for (int part = 0; part < 2; ++part)                                // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
         for (int pl = 0; pl < 2; ++pl)
-            for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < taps; ++t)
                 for (int ct = 0; ct < CT; ++ct)
                     for (int h16 = 0; h16 < 2; ++h16)
                         for (int row = 0; row < 32; ++row)
@@ -918,12 +975,41 @@ void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host) {
                                 const int co = ct * 32 + row, ci = 32 * pl + 16 * h16 + j;
                                 float v = 0.f;
                                 if (co < cout && ci < cin) {
-                                    const float x = w[((size_t)co * cin + ci) * 9 + t];
+                                    const float x = w[((size_t)co * cin + ci) * taps + t];
                                     const float hi = (float)(f16)x;
                                     v = part == 0 ? hi : (x - hi) * 2048.0f;
                                 }
                                 *d++ = f32_to_e4m3(v);
                             }
+}
+
+void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host) { pack_f8hp_taps(w, cin, cout, 9, dst_host); }
+
+size_t conv_wpack_bytes_phase(int cin, int cout) { return (size_t)2 * ((cin + 15) / 16) * 4 * (2 * ((cout + 31) / 32)) * 1024; }
+
+// Sub-pixel kernels of "nearest-2x, then 3x3" (see the PH template parameter): for output parity
+// (py, q) the taps that read the same source pixel are summed (in double), giving a 2x2 kernel on the
+// source image; tap (a, b) sits on source pixel (y + py - 1 + a, x + q - 1 + b).  One pack per row parity:
+// the two column parities are stacked as cout tiles [q = 0 couts | q = 1 couts] (cout padded to 32s).
+void pack_conv_weights_phase_f8hp(const float* w, int cin, int cout, int py, void* dst_host) {
+    const int cpad = ((cout + 31) / 32) * 32;
+    std::vector<float> w4((size_t)2 * cpad * cin * 4, 0.f);
+    auto grp = [](int parity, int a, int d) {   // does original tap index d (0..2) fall on source offset a (0..1)?
+        const int src = (parity + d - 1 + 2) / 2 - 1;      // floor((parity + d - 1) / 2) for values >= -1
+        return src == parity - 1 + a;
+    };
+    for (int q = 0; q < 2; ++q)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        double acc = 0.0;
+                        for (int dy = 0; dy < 3; ++dy)
+                            for (int dx = 0; dx < 3; ++dx)
+                                if (grp(py, a, dy) && grp(q, b, dx)) acc += (double)w[((size_t)co * cin + ci) * 9 + dy * 3 + dx];
+                        w4[((size_t)(q * cpad + co) * cin + ci) * 4 + a * 2 + b] = (float)acc;
+                    }
+    pack_f8hp_taps(w4.data(), cin, 2 * cpad, 4, dst_host);
 }
 
 }  // namespace s2sr

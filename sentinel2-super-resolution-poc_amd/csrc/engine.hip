@@ -24,6 +24,7 @@ struct ConvW {
     int seg_len = 0, seg_lo_mask = 0;   // split-operand convs (precision S2SR_PREC_F16_HP), see ConvParams
     bool fold = false;                  // conv_last in hp mode: w_lo folded into idle couts (pack_conv_weights)
     bool f8 = false;                    // hp mode, cin 64: fp16 main term + e4m3 correction planes (pack_conv_weights_f8hp)
+    void* d_wphase[2] = {nullptr, nullptr};   // hp up-convs: the 2x2 sub-pixel kernels per output row parity (pack_conv_weights_phase_f8hp)
     void* d_wpack = nullptr;
     float* d_bias = nullptr;
 };
@@ -269,6 +270,24 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     return S2SR_OK;
 }
 
+// conv_up1 / conv_up2 in hp mode: "nearest-2x, then 3x3" as four 2x2-tap convs of the source image, one
+// launch per output ROW parity (conv3x3.hip, PH template parameter): 4 MACs per output pixel instead of 9.
+// `p` arrives filled for the upsample-on-load form (src / src_lo / dst / T and their image strides).
+int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams p, int n, int Hs, int Ws, int sHp, int sWp,
+                    int oHp, int oWp) {
+    p.N = n; p.H = Hs; p.W = Ws; p.sHp = sHp; p.sWp = sWp; p.Hp = oHp; p.Wp = oWp;
+    p.bias = cw.d_bias; p.nstage = cw.nstage; p.seg_len = cw.seg_len; p.seg_lo_mask = cw.seg_lo_mask; p.fold_lo = 0;
+    p.trash = h->d_trash;
+    const double px = (double)n * Hs * Ws;
+    for (int k = 0; k < 2; ++k) {
+        p.wpack = cw.d_wphase[k];
+        // statistics keep the nominal work of the 3x3 form (2*9*cin*cout per OUTPUT pixel; one row parity = half of them)
+        Scope sc(h, st, F_UP, 2.0 * 9.0 * cw.cin * cw.cout * 2.0 * px, px * (cw.cin * 4.0 + 2.0 * cw.cout * 4.0));
+        HIPCHK(h, launch_conv_phase(p, k, st));
+    }
+    return S2SR_OK;
+}
+
 // The layer schedule for `n` images already packed into ws.P0.  Exactly the op order of
 // RRDBNet.forward (cnn_super_resolution.py:140-158) with ResidualDenseBlock / RRDB inlined
 // (:85-91, :103-107).  The torch.cat of the dense block is "the first k blocks of D[cur]",
@@ -317,14 +336,18 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
         p.N = n; p.H = 2 * H; p.W = 2 * W; p.Hp = w.Hp2; p.Wp = w.Wp2; p.sHp = w.Hp; p.sWp = w.Wp;
         p.src = w.U0; p.src_img = 4 * w.blk1; p.dst = w.U1; p.dst_img = 4 * w.blk2;
         if (hp) { p.src_lo = w.U0lo; p.lo_img = 4 * w.blk1; p.T = w.U1lo; }
-        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
+        if (h->convs[ci].d_wphase[0]) {
+            if ((rc = run_up_subpixel(h, st, h->convs[ci++], p, n, H, W, w.Hp, w.Wp, w.Hp2, w.Wp2))) return rc;
+        } else if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
     }
     {   // conv_up2 on nearest-2x
         ConvParams p{};
         p.N = n; p.H = 4 * H; p.W = 4 * W; p.Hp = w.Hp4; p.Wp = w.Wp4; p.sHp = w.Hp2; p.sWp = w.Wp2;
         p.src = w.U1; p.src_img = 4 * w.blk2; p.dst = w.U2; p.dst_img = 4 * w.blk4;
         if (hp) { p.src_lo = w.U1lo; p.lo_img = 4 * w.blk2; p.T = w.U2lo; }
-        if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
+        if (h->convs[ci].d_wphase[0]) {
+            if ((rc = run_up_subpixel(h, st, h->convs[ci++], p, n, 2 * H, 2 * W, w.Hp2, w.Wp2, w.Hp4, w.Wp4))) return rc;
+        } else if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
     }
     ConvParams hr{};
     hr.N = n; hr.H = 4 * H; hr.W = 4 * W; hr.Hp = w.Hp4; hr.Wp = w.Wp4; hr.sHp = w.Hp4; hr.sWp = w.Wp4;
@@ -503,6 +526,8 @@ void s2sr_destroy(s2sr_handle* h) {
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
+        for (int k = 0; k < 2; ++k)
+            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
     }
     if (h->ws.base) hipFree(h->ws.base);
     if (h->d_trash) hipFree(h->d_trash);
@@ -532,6 +557,8 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
+        for (int k = 0; k < 2; ++k)
+            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
     }
     h->convs.clear();
     h->has_weights = false;
@@ -560,6 +587,15 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
         else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
         cw.fold = fold;
+        if (f8 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
+            const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
+            std::vector<char> ph(pb);
+            for (int k = 0; k < 2; ++k) {
+                pack_conv_weights_phase_f8hp(pw, s.cin, s.cout, k, ph.data());
+                HIPCHK(h, hipMalloc(&cw.d_wphase[k], pb));
+                HIPCHK(h, hipMemcpy(cw.d_wphase[k], ph.data(), pb, hipMemcpyHostToDevice));
+            }
+        }
         pw += (size_t)s.cin * s.cout * 9;
         HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
         HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));

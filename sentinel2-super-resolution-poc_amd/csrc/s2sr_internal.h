@@ -91,6 +91,10 @@ size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
 // [w_hi ch 0-31][w_hi ch 32-63][w_lo*2^11 ch 0-31][w_lo*2^11 ch 32-63]; an fp8 stage fragment is
 // [tap][ct][16-B half][cout row 0..31][16 channel bytes].  Same size as nseg = 2.
 void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host);
+// sub-pixel form of the split-operand up-convs: four 2x2-tap kernels (one per output parity), same stage layout
+void pack_conv_weights_phase_f8hp(const float* w, int cin, int cout, int phase, void* dst_host);
+size_t conv_wpack_bytes_phase(int cin, int cout);
+hipError_t launch_conv_phase(const ConvParams& p, int phase, hipStream_t st);
 uint8_t f32_to_e4m3(float f);   // OCP e4m3fn, round to nearest even, saturating at +-448
 
 // XYZ tile pyramid (tiles.hip)
