@@ -29,6 +29,9 @@
 //     loader's source offsets (>>1) and never materialised.
 //   * Inside a stage the 9 A fragments stay in registers and every B fragment (slab row s,
 //     column shift dx) is read ONCE and used for all kernel rows dy with 0 <= s-dy < NP.
+//   * Split-operand convs of the high-precision mode (F8): fp16 main term + e4m3 correction planes
+//     on the block-scaled fp8 MFMA, two planes per K=64 instruction (see the F8 / HPO notes at the
+//     kernel); their up-convs run in sub-pixel form (PH): 2x2 taps on the source image.
 #include <math.h>
 #include <stdlib.h>
 
