@@ -174,7 +174,7 @@ template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false
 __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
     static_assert(!F8 || R == 4, "the fp8 pair schedule is written for a 4-slot ring");
-    static_assert(PH < 0 || (F8 && !UP && CT % 2 == 0), "the sub-pixel form is instantiated for the split-operand up-convs");
+    static_assert(PH < 0 || (!UP && CT % 2 == 0 && R == 4), "the sub-pixel form replaces upsample-on-load");
     constexpr int PY = PH >= 0 ? PH : 0;
     constexpr int CTR = PH >= 0 ? CT / 2 : CT;     // real cout tiles; in the sub-pixel form tile ct = q*CTR + rc, q = column parity
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -774,8 +774,11 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 }
                 after_epi = false;
                 S2SR_STAMP(2 + 2 * k);
-                stage_body(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u, r,
-                           st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
+                if constexpr (PH >= 0)
+                    stage16_dx(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u);
+                else
+                    stage_body(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u, r,
+                               st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
                 S2SR_STAMP(3 + 2 * k);
                 if (++st_c == NS) {
                     epilogue(it_c);
@@ -805,6 +808,7 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
     auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH>;
     if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
+    if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
     // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -874,9 +878,14 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
 
 // one ROW parity of a split-operand up-conv in sub-pixel form (both column parities inside the launch;
 // p.H, p.W = source dims, p.Hp, p.Wp = 2x tensor)
-hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st) {
-    if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 0>(p, st);
-    if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 1>(p, st);
+hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f8) {
+    if (f8) {
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 1>(p, st);
+    } else {   // plain fp16 mode: the same four fp16 stages, no correction planes in or out
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, false, 1, false, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, false, 1, false, 1>(p, st);
+    }
     return hipErrorInvalidValue;
 }
 

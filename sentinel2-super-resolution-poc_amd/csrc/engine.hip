@@ -276,14 +276,14 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
 int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams p, int n, int Hs, int Ws, int sHp, int sWp,
                     int oHp, int oWp) {
     p.N = n; p.H = Hs; p.W = Ws; p.sHp = sHp; p.sWp = sWp; p.Hp = oHp; p.Wp = oWp;
-    p.bias = cw.d_bias; p.nstage = cw.nstage; p.seg_len = cw.seg_len; p.seg_lo_mask = cw.seg_lo_mask; p.fold_lo = 0;
+    p.bias = cw.d_bias; p.nstage = cw.f8 ? 8 : 4; p.seg_len = 4; p.seg_lo_mask = cw.f8 ? 0x2 : 0x0; p.fold_lo = 0;
     p.trash = h->d_trash;
     const double px = (double)n * Hs * Ws;
     for (int k = 0; k < 2; ++k) {
         p.wpack = cw.d_wphase[k];
         // statistics keep the nominal work of the 3x3 form (2*9*cin*cout per OUTPUT pixel; one row parity = half of them)
         Scope sc(h, st, F_UP, 2.0 * 9.0 * cw.cin * cw.cout * 2.0 * px, px * (cw.cin * 4.0 + 2.0 * cw.cout * 4.0));
-        HIPCHK(h, launch_conv_phase(p, k, st));
+        HIPCHK(h, launch_conv_phase(p, k, st, cw.f8));
     }
     return S2SR_OK;
 }
@@ -587,7 +587,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
         else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
         cw.fold = fold;
-        if (f8 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
+        if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
             const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
             std::vector<char> ph(pb);
             for (int k = 0; k < 2; ++k) {

@@ -94,7 +94,7 @@ void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host);
 // sub-pixel form of the split-operand up-convs: four 2x2-tap kernels (one per output parity), same stage layout
 void pack_conv_weights_phase_f8hp(const float* w, int cin, int cout, int phase, void* dst_host);
 size_t conv_wpack_bytes_phase(int cin, int cout);
-hipError_t launch_conv_phase(const ConvParams& p, int phase, hipStream_t st);
+hipError_t launch_conv_phase(const ConvParams& p, int row_parity, hipStream_t st, bool f8);
 uint8_t f32_to_e4m3(float f);   // OCP e4m3fn, round to nearest even, saturating at +-448
 
 // XYZ tile pyramid (tiles.hip)
