@@ -883,8 +883,8 @@ hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f
         if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 0>(p, st);
         if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 1>(p, st);
     } else {   // plain fp16 mode: the same four fp16 stages, no correction planes in or out
-        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, false, 1, false, 0>(p, st);
-        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, false, 1, false, 1>(p, st);
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, false, 1, false, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, false, 1, false, 1>(p, st);
     }
     return hipErrorInvalidValue;
 }
