@@ -237,6 +237,8 @@ def main():
                                    + (", + RCCL all-gather of output tiles" if world > 1 else ""),
                        "tiles_per_s": round(tiles_per_s, 2), "input_MP_per_s": round(value / 16, 3),
                        "net_TFLOP_per_s_per_gpu": round(tiles_per_s / world * TILE * TILE * FLOP_PER_LR_PX / 1e12, 1),
+                       "flop_note": "TFLOP/s figures count the reference net's FLOPs (2*9*Cin*Cout per output pixel); the two "
+                                    "up-convs execute 4/9 of theirs (sub-pixel form), 2.3 % of the net",
                        "group": a.group, "weights": "seeded synthetic RealESRGAN_x4plus shapes (seed 0)",
                        "precision": ("fp16 MFMA operands, fp32 accumulate, trunk as fp16 hi/lo pair; the 6 convs outside the "
                                      "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 7e-5..1.2e-4 vs the fp32 reference"
