@@ -385,3 +385,29 @@ def test_hp_tolerance_holds_for_other_weight_draws(seed, gain):
     d = np.abs(q.astype(np.int16) - q_ref.astype(np.int16))
     print(f"seed {seed} gain {gain}: float err {err:.3e} (|y| max {np.abs(f_ref).max():.2f}), u8 identical {np.mean(d == 0):.4f}")
     assert err <= TOL_HP and d.max() <= 1 and np.mean(d == 0) >= 0.99
+
+
+def test_subpixel_and_upsample_on_load_forms_agree(monkeypatch):
+    """The up-convs run in sub-pixel form (2x2 taps on the source image); S2SR_NO_SUBPIXEL=1 keeps the
+    3x3-on-upsampled loader form.  Both must match the oracle, and each other to fp32-rounding level."""
+    nb = 2
+    sd = synthetic_state_dict(nb, seed=4)
+    tsd = ref.to_torch_sd(sd)
+    img = np.random.default_rng(77).integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    _, f_ref = ref.enhance(img, tsd, nb, return_float=True)
+    for prec, tol in ((native.PREC_F16_HP, TOL_HP), (native.PREC_F16, TOL_F16)):
+        outs = []
+        for flag in ("0", "1"):
+            if flag == "1":
+                monkeypatch.setenv("S2SR_NO_SUBPIXEL", "1")
+            else:
+                monkeypatch.delenv("S2SR_NO_SUBPIXEL", raising=False)
+            e = native.Engine(num_block=nb, precision=prec)
+            e.load_state_dict(sd)
+            outs.append(e.enhance_f32(img))
+            e.close()
+            assert np.abs(outs[-1] - f_ref).max() <= tol, (prec, flag)
+        d = np.abs(outs[0] - outs[1]).max()
+        print(f"precision {prec}: sub-pixel vs upsample-on-load max diff {d:.2e}")
+        assert d <= (5e-5 if prec == native.PREC_F16_HP else 2e-3)
+    monkeypatch.delenv("S2SR_NO_SUBPIXEL", raising=False)
