@@ -150,9 +150,35 @@ def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str)
         return eng
 
 
+_THREAD = threading.local()
+
+
+class thread_device:
+    """`with thread_device(i):` -- jobs started on this thread resolve `device=None` to GPU i.  The
+    reference's callers never pass a device (wow_sr.py:93, farm_sr.py:162), so this is how the admission
+    queue (app.sr_routes.GpuAdmission) puts a job on the GPU it was admitted to."""
+
+    def __init__(self, index: int):
+        self.index = int(index)
+
+    def __enter__(self):
+        self.prev = getattr(_THREAD, "device", None)
+        _THREAD.device = self.index
+        return self
+
+    def __exit__(self, *exc):
+        _THREAD.device = self.prev
+        return False
+
+
+def current_device_index() -> int:
+    d = getattr(_THREAD, "device", None)
+    return int(os.environ.get("LOCAL_RANK", "0")) if d is None else d
+
+
 def _resolve_device(device) -> torch.device:
     if device is None:
-        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        return torch.device("cuda", current_device_index())
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError(f"device {device!r}: this build runs the network on an MI355X only; "

@@ -1,6 +1,6 @@
 """Minimal HTTP harness for the SR handler surface of the reference
 (reference server/app/main.py:192-235 request/response models, :247-368 job runners,
-:371-449 `/api/sr`, :457-541 `/api/wow`).  It exists so that the handler contract -- routes,
+:371-449 `/api/sr`, :457-541 `/api/wow`, :544-675 `/api/enhance` + its admission queue).  It exists so that the handler contract -- routes,
 request fields, validation codes, job-table fields and status strings
 `queued -> [fetching] -> processing -> tiling -> completed | failed` -- can be exercised against
 the GPU path in tests; it is NOT a port of the server.  Out of scope and therefore hooks:
@@ -14,12 +14,16 @@ the GPU path in tests; it is NOT a port of the server.  Out of scope and therefo
 from __future__ import annotations
 
 import threading
+from collections import deque
 from datetime import datetime
+from email.parser import BytesParser
 from pathlib import Path
-from typing import Callable, Optional
+from typing import Callable, List, Optional
 
-from fastapi import BackgroundTasks, FastAPI, HTTPException
+from fastapi import BackgroundTasks, FastAPI, HTTPException, Request
 from pydantic import BaseModel
+
+MAX_UPLOAD_BYTES = 50 * 1024 * 1024          # main.py:68 (settings.max_upload_bytes default)
 
 
 class SRRequest(BaseModel):          # main.py:192-197
@@ -43,9 +47,87 @@ class SRResponse(BaseModel):         # main.py:230-235
     message: str
 
 
+class GpuAdmission:
+    """Admission queue of `/api/enhance` (reference main.py:62-70, 602-616, 629-675), GPU-aware.
+
+    The reference admits MAX_CONCURRENT_ENHANCE (= 1) jobs whatever the hardware and parks the rest in
+    `pending_enhance_queue`; a finished job starts the head of the queue from a raw daemon thread.  Here the
+    unit of capacity is a GPU: one in-flight job per device of `devices`, FIFO for the rest, and the job a
+    device takes on runs on THAT device (the thread's device ordinal is what `RealESRGAN(device=None)` and the
+    post-process resolve to, app.cnn_super_resolution.thread_device).  All state sits behind one lock --
+    the reference mutates its set/deque from request and worker threads unguarded."""
+
+    def __init__(self, devices: List[int]):
+        if not devices:
+            raise ValueError("GpuAdmission needs at least one device ordinal")
+        self.devices = list(devices)
+        self._free = deque(self.devices)
+        self._busy = {}                  # job_id -> device
+        self._pending = deque()          # (job_id, run) in arrival order
+        self._lock = threading.Lock()
+
+    def submit(self, job_id: str, run: Callable[[int], None]) -> Optional[int]:
+        """-> device ordinal when admitted now (the caller starts `run_admitted`), None when queued."""
+        with self._lock:
+            if self._free:
+                dev = self._free.popleft()
+                self._busy[job_id] = dev
+                return dev
+            self._pending.append((job_id, run))
+            return None
+
+    def run_admitted(self, job_id: str, run: Callable[[int], None], on_start: Optional[Callable[[str], None]] = None):
+        """Body of an admitted job's thread: run on the device it holds, then hand the device to the
+        head of the queue (started from a daemon thread, as the reference does, main.py:661-675)."""
+        from app.cnn_super_resolution import thread_device
+        with self._lock:
+            dev = self._busy[job_id]
+        try:
+            with thread_device(dev):
+                run(dev)
+        finally:
+            nxt = None
+            with self._lock:
+                del self._busy[job_id]
+                if self._pending:
+                    nxt = self._pending.popleft()
+                    self._busy[nxt[0]] = dev
+                else:
+                    self._free.append(dev)
+            if nxt is not None:
+                if on_start:
+                    on_start(nxt[0])
+                threading.Thread(target=self.run_admitted, args=(nxt[0], nxt[1], on_start), daemon=True).start()
+
+    def snapshot(self) -> dict:
+        with self._lock:
+            return {"devices": list(self.devices), "active": dict(self._busy), "pending": [j for j, _ in self._pending]}
+
+
+def _parse_multipart(content_type: str, body: bytes) -> dict:
+    """multipart/form-data -> {field: (filename or None, bytes)}.  (python-multipart, which FastAPI's
+    File()/Form() need, is not a dependency of this build; the stdlib MIME parser does the same job.)"""
+    if "multipart/form-data" not in (content_type or "").lower():
+        raise HTTPException(status_code=422, detail="expected multipart/form-data with an `image` file field")
+    msg = BytesParser().parsebytes(b"Content-Type: " + content_type.encode() + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
+    out = {}
+    if msg.is_multipart():
+        for part in msg.get_payload():
+            name = part.get_param("name", header="content-disposition")
+            if name:
+                out[name] = (part.get_filename(), part.get_payload(decode=True) or b"")
+    return out
+
+
 def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optional[Callable] = None, tiler=None,
-               tile_min_zoom: int = 10, tile_max_zoom: int = 16) -> FastAPI:
+               tile_min_zoom: int = 10, tile_max_zoom: int = 16, devices: Optional[List[int]] = None,
+               max_upload_bytes: int = MAX_UPLOAD_BYTES) -> FastAPI:
     app = FastAPI(title="s2sr SR handler harness")
+    if devices is None:
+        import os
+        devices = [int(os.environ.get("LOCAL_RANK", "0"))]      # one process per GPU: this process's GPU
+    admission = GpuAdmission(devices)
+    app.state.admission = admission
     data_dir = Path(data_dir)
     source_dir = Path(source_dir) if source_dir else data_dir / "source"
     sr_jobs: dict = {}
@@ -169,5 +251,59 @@ def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optio
         msg = (f"WOW SR started: {input_file.name} -> Real-ESRGAN x4 + Enhanced" if input_file else
                f"WOW SR started: auto-fetching best image (last {request.max_age_days}d, cloud <={request.max_cloud_cover}%)")
         return SRResponse(job_id=job_id, status="queued", message=msg)
+
+    # ---- /api/enhance: upload + admission queue (main.py:544-675) ------------------------------------
+    def run_wow_job_wrapper(job_id, input_path, output_dir, enhance_crops, model):
+        def run(dev):
+            _set(job_id, status="processing", message="Running enhancement", device=dev)
+            run_wow_job(job_id, input_path, output_dir, enhance_crops, auto_fetch=False, model=model)
+        return run
+
+    def _mark_started(job_id):
+        _set(job_id, status="processing", message="Starting from queue")
+
+    @app.post("/api/enhance")
+    async def enhance_image_upload(request: Request, background_tasks: BackgroundTasks):
+        body = await request.body()
+        fields = _parse_multipart(request.headers.get("content-type", ""), body)
+        model = (fields.get("model", (None, b"realesrgan_x4"))[1] or b"realesrgan_x4").decode("utf-8", "replace").strip()
+        valid_models = ["realesrgan_x4", "realesrgan_anime"]
+        if model not in valid_models:
+            raise HTTPException(status_code=400, detail=f"Invalid model. Choose from: {valid_models}")
+        if "image" not in fields or fields["image"][0] is None:
+            raise HTTPException(status_code=422, detail="field `image` (file) is required")
+        filename, content = fields["image"]
+        if len(content) > max_upload_bytes:
+            raise HTTPException(status_code=413,
+                                detail=f"Upload exceeds maximum allowed size of {max_upload_bytes // (1024 * 1024)} MB")
+        try:
+            with lock:                       # ids have 1 s resolution in the reference; keep them unique here
+                base = f"wow_{datetime.now().strftime('%Y%m%d_%H%M%S')}"
+                job_id, n = base, 1
+                while job_id in sr_jobs:
+                    job_id, n = f"{base}_{n}", n + 1
+                sr_jobs[job_id] = {}
+            output_dir = data_dir / "wow" / job_id
+            upload_dir = data_dir / "uploads" / job_id
+            output_dir.mkdir(parents=True, exist_ok=True)
+            upload_dir.mkdir(parents=True, exist_ok=True)
+            uploaded_path = upload_dir / Path(filename).name       # never trust a client path
+            uploaded_path.write_bytes(content)
+            _set(job_id, status="queued", message="Enhancement queued", input_file=str(uploaded_path),
+                 output_dir=str(output_dir), model=model, created_at=datetime.now().isoformat())
+            run = run_wow_job_wrapper(job_id, uploaded_path, output_dir, True, model)
+            dev = admission.submit(job_id, run)
+            if dev is not None:
+                _set(job_id, status="processing", message="Enhancement starting", device=dev)
+                background_tasks.add_task(admission.run_admitted, job_id, run, _mark_started)
+            else:
+                _set(job_id, status="queued", message="Queued due to concurrency limits")
+            with lock:
+                st = dict(sr_jobs[job_id])
+            return {"job_id": job_id, "status": st["status"], "message": st["message"], "model": model}
+        except HTTPException:
+            raise
+        except Exception as e:                                               # noqa: BLE001 -- main.py:624-626
+            raise HTTPException(status_code=500, detail=str(e))
 
     return app

@@ -17,8 +17,12 @@ _PP_LOCK = threading.Lock()
 _PP_ENGINE = {}
 
 
-def _pp_engine(device_index: int = 0) -> native.Engine:
-    """Handle used for post-process only (it needs no weights)."""
+def _pp_engine(device_index: int = None) -> native.Engine:
+    """Handle used for post-process only (it needs no weights); one per GPU, shared by all jobs
+    (s2sr_postprocess_u8 holds the handle's lock from upload to download)."""
+    if device_index is None:
+        from app.cnn_super_resolution import current_device_index
+        device_index = current_device_index()
     with _PP_LOCK:
         if device_index not in _PP_ENGINE:
             _PP_ENGINE[device_index] = native.Engine(num_block=1, device=device_index)

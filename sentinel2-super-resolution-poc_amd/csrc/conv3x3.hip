@@ -35,6 +35,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "s2sr_internal.h"
@@ -104,16 +105,25 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t voff, uint32_t
 
 // 16-B global load hidden from hipcc's waitcnt bookkeeping; valid only after an explicit
 // s_waitcnt vmcnt(0) (asm) that the caller places before the first use.
+// The destination is an ACCUMULATION register ("a"; gfx90a+ vector-memory instructions may target
+// AGPRs): the compiler does not know the value is still in flight, so whatever it does with the
+// register before the wait must be nothing.  With "=v" and more than 256 live registers (the one-wave-
+// per-SIMD forms) hipcc parked freshly "loaded" VGPRs in AGPRs right behind the asm statement -- it
+// copied bytes that had not arrived, handed the VGPR to someone else (an address), and the load then
+// landed on top of it: the memory fault of r01's 4-wave variant.  asm_land() after the wait ties the
+// value to a statement behind the wait, so every consumer (and every copy to a VGPR) comes after it.
 __device__ __forceinline__ f32x4 asm_load16(const float* addr) {
     f32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(r) : "v"(addr) : "memory");
     return r;
 }
+template <typename T>
+__device__ __forceinline__ void asm_land(T& r) { asm volatile("" : "+a"(r)); }
 
 // LeakyReLU(0.2): max(v, 0.2v) is the same value for every finite v and one VALU op shorter
 __device__ __forceinline__ u32x2 asm_load8(const char* addr) {
     u32x2 r;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(r) : "v"(addr) : "memory");
     return r;
 }
 __device__ __forceinline__ f32x4 half4_to_float(u32x2 h) {
@@ -147,8 +157,15 @@ __device__ __forceinline__ void wait_vm_barrier() {
 
 #define S2SR_STAMP(k)                                                              \
     do {                                                                           \
-        if (TRACE && p.trace && tid == 0 && (k) < 20)                              \
+        if (TRACE && p.trace && !(p.dbg & 4) && tid == 0 && (k) < 20)              \
             p.trace[(size_t)blockIdx.x * 24 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// dbg & 4: per-wave anatomy of steady-state stage 5 instead (tools/trace_waves.py): slot 0 = leaves the
+// barrier before stage 5, slot 2 = has issued its last MFMA of stage 5, slot 1 = leaves the barrier before stage 6
+#define S2SR_WSTAMP(slot)                                                                                 \
+    do {                                                                                                  \
+        if (TRACE && p.trace && (p.dbg & 4) && lane == 0)                                                 \
+            p.trace[(size_t)blockIdx.x * 24 + (slot) * 8 + wave] = __builtin_amdgcn_s_memtime();          \
     } while (0)
 
 // F8 (split-operand consumers, S2SR_PREC_F16_HP): a patch is 8 stages -- 4 fp16 blocks of x_hi
@@ -184,7 +201,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pcol = lane & 31, hh = lane >> 5;
     S2SR_STAMP(0);
-    if (TRACE && p.trace && tid == 0) {
+    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {
         p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
     }
@@ -364,6 +381,15 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                     acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dy * 3 + dx][ct], b[step % (D + 1)], acc[ct][np], 0, 0, 0);
             }
         }
+        // one wave per SIMD (512 registers): the accumulators live in AGPRs.  Left alone, hipcc moves every
+        // finished accumulator to VGPRs and back once per stage (~7 v_accvgpr moves per MFMA) because the
+        // epilogue behind the loop wants them in VGPRs; this pins them where the MFMAs want them.
+        if (WAVES == 4) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int np = 0; np < NP; ++np) asm volatile("" : "+a"(acc[ct][np]));
+        }
     };
 
     // ---- F8 kernels: both stage kinds walk dx -> slab row -> dy, so only the three A fragments of one
@@ -540,10 +566,21 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         res1[ct][np][g] = asm_load16((const float*)((const char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16));
                 }
         };
+        auto land_res = [&](int np) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    asm_land(lo_old[ct][np][g]);
+                    if (EPI == EPI_RDB5_RRDB) asm_land(res1[ct][np][g]);
+                }
+        };
         if (EPI == EPI_RDB5) {
 #pragma unroll
             for (int np = 0; np < NP; ++np) load_res(np);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int np = 0; np < NP; ++np) land_res(np);
             __builtin_amdgcn_sched_barrier(0);
         } else if (EPI == EPI_BODY) {
 #pragma unroll
@@ -560,6 +597,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             if (EPI == EPI_RDB5_RRDB) {
                 load_res(np);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                land_res(np);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -774,12 +812,15 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 }
                 after_epi = false;
                 S2SR_STAMP(2 + 2 * k);
+                if (k == 5) S2SR_WSTAMP(0);
+                if (k == 6) S2SR_WSTAMP(1);
                 if constexpr (PH >= 0)
                     stage16_dx(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u);
                 else
                     stage_body(smem + r * G::STAGE_BYTES, (k + (R - 1) < S) ? 1 : 0, (uint32_t)(((r + R - 1) % R) * G::STAGE_BYTES), 0u, r,
                                st_c == r);   // NS % R == 0 for the trunk forms: stages 0..3 of a patch sit in slots 0..3
                 S2SR_STAMP(3 + 2 * k);
+                if (k == 5) S2SR_WSTAMP(2);
                 if (++st_c == NS) {
                     epilogue(it_c);
                     init_acc();
@@ -791,7 +832,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             }
         }
     }
-    if (TRACE && p.trace && tid == 0) {
+    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {
         p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
     }
@@ -809,21 +850,27 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH>;
     if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
     if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
-    // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs
+    // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs, driven from
+    // different threads (each handle has its own mutex, so this table needs one of its own)
+    static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        int n = 256;
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        ncu_dev[dev] = n;
-        attr_set[dev] = true;
+    int ncu;
+    {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            int n = 256;
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            ncu_dev[dev] = n;
+            attr_set[dev] = true;
+        }
+        ncu = ncu_dev[dev];
     }
-    const int ncu = ncu_dev[dev];
     if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage % R != 0 || p.nstage < 4))
         return hipErrorInvalidValue;   // the trunk forms pick x out of ring slots 0..3 (see hi_cap)
     ConvParams q = p;
@@ -838,9 +885,27 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// S2SR_W4=1: the RDB convs as 4-wave workgroups, one wave per SIMD with the 512-register budget
+// (8 / 4 rows per wave), instead of 8 waves x 4 / 2 rows
+static bool use_w4() {
+    static const bool v = [] { const char* e = getenv("S2SR_W4"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     constexpr int R = (CT == 1) ? 5 : 4;
+    if constexpr (!UP && ((CT == 1 && EPI == EPI_LRELU) || (CT == 2 && (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB)))) {
+        if (use_w4()) {
+            if constexpr (CT == 1) {
+                const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
+                if (n32 >= 192) return launch_t<1, EPI_LRELU, false, 4, 8, 3>(p, st);
+                return launch_t<1, EPI_LRELU, false, 4, 4, 5>(p, st);
+            } else {
+                return launch_t<2, EPI, false, 4, 4, 4>(p, st);
+            }
+        }
+    }
     if (CT == 1 && EPI == EPI_LRELU && !UP) {
         // the 32-cout RDB convs: 32x32 patch (4 rows per wave), 3-deep ring -- unless that leaves most
         // CUs without a patch (single tiles): then the 16x32 patch spreads the image over twice as
@@ -890,6 +955,10 @@ hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f
 }
 
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
+    if (use_w4()) {
+        if (ct == 1) return launch_t<1, EPI_LRELU, false, 4, 8, 3, true>(p, st);
+        return launch_t<2, EPI_RDB5, false, 4, 4, 4, true>(p, st);
+    }
     if (ct == 1) return launch_t<1, EPI_LRELU, false, 8, 4, 3, true>(p, st);
     return launch_t<2, EPI_RDB5, false, 8, 2, 4, true>(p, st);
 }

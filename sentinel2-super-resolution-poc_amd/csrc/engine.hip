@@ -611,6 +611,35 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     return S2SR_OK;
 }
 
+// Device-resident blob (what an RCCL broadcast leaves on every rank): staged through pinned host memory
+// inside the library, because the repack to MFMA fragment order (pack_conv_weights*) is host code.  One
+// 67 MB copy per model load; the caller never touches host memory.
+int s2sr_load_weights_dev(s2sr_handle* h, const void* d_blob, size_t n_floats, void* stream) {
+    if (!h || !d_blob) return S2SR_E_INVALID;
+    float* host = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        HIPCHK(h, hipSetDevice(h->cfg.device));
+        const size_t want = s2sr_expected_blob_floats(h->cfg.num_block);
+        if (n_floats != want) {
+            char b[160];
+            snprintf(b, sizeof b, "weight blob has %zu floats, a %d-block net needs %zu", n_floats, h->cfg.num_block, want);
+            return fail(h, S2SR_E_BADBLOB, b);
+        }
+        HIPCHK(h, hipHostMalloc((void**)&host, n_floats * sizeof(float), hipHostMallocDefault));
+        hipStream_t st = (hipStream_t)stream;
+        hipError_t e = hipMemcpyAsync(host, d_blob, n_floats * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            hipHostFree(host);
+            return fail(h, S2SR_E_HIP, std::string("copy of the device blob failed: ") + hipGetErrorString(e));
+        }
+    }
+    const int rc = s2sr_load_weights(h, host, n_floats);
+    hipHostFree(host);
+    return rc;
+}
+
 int s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t scale, s2sr_window* out, int32_t cap,
                     int32_t* n) {
     if (H <= 0 || W <= 0 || tile <= 0 || pad < 0 || scale <= 0 || !n) return S2SR_E_INVALID;
@@ -921,12 +950,9 @@ int s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t
     return enhance_impl(h, img, H, W, tile, pad, nullptr, out, true);
 }
 
-int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
-                                  const s2sr_pp_params* prm, void* d_out, void* stream) {
-    if (!h || !d_rgb || !d_out || !prm || B <= 0 || H <= 0 || W <= 0) return S2SR_E_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
-    hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
+// post-process on device buffers; the caller holds h->mu
+static int postprocess_dev_locked(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W, const s2sr_pp_params* prm,
+                                  void* d_out, hipStream_t st) {
     const size_t wb = postprocess_work_bytes(B, H, W, *prm);
     int rc = ensure_scratch(h, 5, wb);
     if (rc) return rc;
@@ -935,20 +961,27 @@ int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, 
     return S2SR_OK;
 }
 
+int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
+                                  const s2sr_pp_params* prm, void* d_out, void* stream) {
+    if (!h || !d_rgb || !d_out || !prm || B <= 0 || H <= 0 || W <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return postprocess_dev_locked(h, d_rgb, B, H, W, prm, d_out, (hipStream_t)stream);   // NULL = the default stream, as everywhere in HIP
+}
+
+// Host image in, host image out.  ONE lock scope from the upload to the download: the staging buffers
+// (d_scratch[0], [1]) belong to the handle, and the app shares one post-process handle per device between
+// all jobs (app/wow_sr.py), which the reference runs from concurrent worker threads (main.py:247-368).
 int s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, const s2sr_pp_params* prm, uint8_t* out) {
     if (!h || !rgb || !out || !prm || H <= 0 || W <= 0) return S2SR_E_INVALID;
     const size_t nb = (size_t)H * W * 3;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        HIPCHK(h, hipSetDevice(h->cfg.device));
-        int rc = ensure_scratch(h, 0, nb);
-        if (rc) return rc;
-        if ((rc = ensure_scratch(h, 1, nb))) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgb, nb, hipMemcpyHostToDevice, h->stream));
-    }
-    int rc = s2sr_postprocess_batch_u8_dev(h, h->d_scratch[0], 1, H, W, prm, h->d_scratch[1], (void*)h->stream);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = ensure_scratch(h, 0, nb);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(h, 1, nb))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgb, nb, hipMemcpyHostToDevice, h->stream));
+    if ((rc = postprocess_dev_locked(h, h->d_scratch[0], 1, H, W, prm, h->d_scratch[1], h->stream))) return rc;
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], nb, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return S2SR_OK;

@@ -64,6 +64,7 @@ _PROTOS = {
     "s2sr_last_error": (C.c_char_p, [C.c_void_p]),
     "s2sr_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "s2sr_expected_blob_floats": (C.c_size_t, [C.c_int32]),
+    "s2sr_load_weights_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "s2sr_plan_tiles": (C.c_int, [C.c_int32] * 5 + [C.POINTER(Window), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_forward_batch_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_forward_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -195,6 +196,11 @@ class Engine:
     def load_blob(self, blob: np.ndarray):
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         self._check(self._lib.s2sr_load_weights(self._h, _ptr(blob), blob.size), "s2sr_load_weights")
+
+    def load_blob_dev(self, d_blob: int, n_floats: int, stream: int = 0):
+        """Device pointer to the fp32 blob (e.g. the tensor an RCCL broadcast filled)."""
+        self._check(self._lib.s2sr_load_weights_dev(self._h, C.c_void_p(d_blob), n_floats, C.c_void_p(stream)),
+                    "s2sr_load_weights_dev")
 
     def load_state_dict(self, sd):
         from .weights import flatten_state_dict

@@ -1,5 +1,7 @@
 """Host-side mirror of the reference seam (app.*): names, errors, state-dict compatibility and
 the PIL raster I/O -- everything that does not need a GPU."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -95,3 +97,129 @@ def test_sr_routes_validation(tmp_path):
     assert r.status_code == 200 and r.json()["status"] == "queued" and r.json()["job_id"].startswith("wow_")
     st = c.get(f"/api/sr/{r.json()['job_id']}").json()
     assert st["status"] == "failed" and "fetcher" in st["message"] and st["pipeline"] == "RealESRGAN_x4 + Enhanced"
+
+
+def _multipart(fields):
+    """Hand-rolled multipart/form-data body: {name: (filename or None, bytes)}."""
+    b = "XbOuNdArY123"
+    out = b""
+    for name, (fn, data) in fields.items():
+        disp = f'form-data; name="{name}"' + (f'; filename="{fn}"' if fn else "")
+        out += (f"--{b}\r\nContent-Disposition: {disp}\r\n" + ("Content-Type: application/octet-stream\r\n" if fn else "")
+                + "\r\n").encode() + data + b"\r\n"
+    out += f"--{b}--\r\n".encode()
+    return out, {"content-type": f"multipart/form-data; boundary={b}"}
+
+
+def test_enhance_upload_validation_and_queue(tmp_path, monkeypatch):
+    """/api/enhance (reference main.py:544-675) without a GPU: validation codes, the upload lands on disk
+    under uploads/<job>/ with the client's file NAME only, jobs beyond the device list queue FIFO and are
+    started by the job that frees a device, on that device."""
+    import threading
+    from fastapi.testclient import TestClient
+    import app.wow_sr as wow
+    from app.cnn_super_resolution import current_device_index
+    from app.sr_routes import create_app
+
+    gate = threading.Event()
+    seen = []
+
+    def fake_process(input_tif, output_dir, enhance_crops=True, model="realesrgan_x4"):
+        seen.append((str(input_tif), model, current_device_index(), enhance_crops))
+        gate.wait(10)
+        return {"outputs": {"sr_tif": None, "sr_png": None}, "sr_metadata": {}}
+
+    monkeypatch.setattr(wow, "process_wow_sr", fake_process)
+    app = create_app(tmp_path / "data", tiler=False, devices=[3], max_upload_bytes=1000)
+    c = TestClient(app)
+    body, hdr = _multipart({"image": ("a.png", b"x" * 10), "model": (None, b"realesrgan_x2")})
+    assert c.post("/api/enhance", content=body, headers=hdr).status_code == 400          # model not in {x4, anime}
+    body, hdr = _multipart({"image": ("a.png", b"x" * 1001)})
+    assert c.post("/api/enhance", content=body, headers=hdr).status_code == 413          # over the upload cap
+    body, hdr = _multipart({"model": (None, b"realesrgan_x4")})
+    assert c.post("/api/enhance", content=body, headers=hdr).status_code == 422          # no file
+    assert c.post("/api/enhance", content=b"{}", headers={"content-type": "application/json"}).status_code == 422
+
+    # three uploads on a one-GPU admission list: the TestClient runs background tasks before returning, so
+    # drive the first from a thread and watch the other two queue
+    results = {}
+
+    def post(tag, name, model):
+        b, h = _multipart({"image": (name, b"img-" + tag.encode()), "model": (None, model.encode())})
+        results[tag] = c.post("/api/enhance", content=b, headers=h).json()
+
+    t1 = threading.Thread(target=post, args=("one", "../../evil/one.png", "realesrgan_anime"))
+    t1.start()
+    for _ in range(200):
+        if seen:
+            break
+        threading.Event().wait(0.02)
+    assert seen and seen[0][1] == "realesrgan_anime" and seen[0][2] == 3 and seen[0][3] is True
+    assert Path(seen[0][0]).name == "one.png" and "uploads" in seen[0][0] and "evil" not in seen[0][0]
+    assert Path(seen[0][0]).read_bytes() == b"img-one"
+    post("two", "two.jpg", "realesrgan_x4")
+    post("three", "three.tif", "realesrgan_x4")
+    assert results["two"]["status"] == "queued" and results["two"]["message"] == "Queued due to concurrency limits"
+    assert results["three"]["status"] == "queued" and len({results["two"]["job_id"], results["three"]["job_id"]}) == 2
+    snap = app.state.admission.snapshot()
+    assert snap["pending"] == [results["two"]["job_id"], results["three"]["job_id"]] and len(snap["active"]) == 1
+    gate.set()
+    t1.join(10)
+    assert results["one"]["status"] == "processing" and results["one"]["model"] == "realesrgan_anime"
+    for _ in range(300):
+        jobs = c.get("/api/sr").json()["jobs"]
+        if all(j["status"] == "completed" for j in jobs.values()) and len(jobs) == 3:
+            break
+        threading.Event().wait(0.02)
+    assert [Path(s[0]).name for s in seen] == ["one.png", "two.jpg", "three.tif"]          # FIFO
+    assert all(s[2] == 3 for s in seen)                                                    # on the admitted device
+    snap = app.state.admission.snapshot()
+    assert snap["active"] == {} and snap["pending"] == []
+    assert all(j["status"] == "completed" for j in jobs.values())
+
+
+def test_gpu_admission_two_devices():
+    """Two devices: two jobs run at once on different GPUs, the third waits for whichever frees first."""
+    import threading
+    from app.sr_routes import GpuAdmission
+    adm = GpuAdmission([0, 1])
+    gates = {k: threading.Event() for k in "abc"}
+    ran = {}
+
+    def job(k):
+        def run(dev):
+            ran[k] = dev
+            gates[k].wait(10)
+        return run
+
+    threads = []
+    for k in "abc":
+        r = job(k)
+        dev = adm.submit(k, r)
+        if dev is not None:
+            t = threading.Thread(target=adm.run_admitted, args=(k, r))
+            t.start()
+            threads.append(t)
+        else:
+            assert k == "c"
+    for _ in range(200):
+        if len(ran) == 2:
+            break
+        threading.Event().wait(0.01)
+    assert ran == {"a": 0, "b": 1} and adm.snapshot()["pending"] == ["c"]
+    gates["b"].set()                       # device 1 frees first -> c runs there
+    for _ in range(200):
+        if "c" in ran:
+            break
+        threading.Event().wait(0.01)
+    assert ran["c"] == 1
+    gates["a"].set(); gates["c"].set()
+    for t in threads:
+        t.join(10)
+    for _ in range(200):
+        if not adm.snapshot()["active"]:
+            break
+        threading.Event().wait(0.01)
+    assert adm.snapshot() == {"devices": [0, 1], "active": {}, "pending": []}
+    with pytest.raises(ValueError):
+        GpuAdmission([])

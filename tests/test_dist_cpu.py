@@ -37,6 +37,9 @@ class FakeBackend:
         t = ((tiles.to(torch.int32) * 3 + 7) % 256).to(torch.uint8)
         return t.repeat_interleave(4, 1).repeat_interleave(4, 2)
 
+    def postprocess(self, img, prm):
+        return 255 - img                 # stand-in for the image-global post-process
+
     def stitch(self, tiles, H, W, tile, pad):
         from s2sr import native
         wins = native.plan_tiles(H, W, tile, pad, 4)
@@ -71,7 +74,14 @@ def _worker(rank, world, port, cases, q):
         res.append(sd.enhance_distributed(be, img, tile, pad))
     tiles = np.random.default_rng(99).integers(0, 256, (5, 8, 12, 3), dtype=np.uint8)
     res.append(sd.forward_batch_distributed(be, tiles))
-    blob = sd.broadcast_weights(synthetic_state_dict(1, seed=3) if rank == 0 else None, 1, torch.device("cpu"))
+    # gather-to-one-consumer form (+ the image-global post-process composed behind the stitch)
+    H, W, tile, pad, seed = cases[0]
+    img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    g = sd.enhance_distributed(be, img, tile, pad, dst=world - 1, enhance_crops=object())
+    assert (g is None) == (rank != world - 1)
+    if rank == world - 1:
+        assert np.array_equal(g, (255 - res[0][:, :, ::-1])[:, :, ::-1])
+    blob = sd.broadcast_weights(synthetic_state_dict(1, seed=3) if rank == 0 else None, 1, torch.device("cpu")).numpy()
     ok_blob = np.array_equal(blob, flatten_state_dict(synthetic_state_dict(1, seed=3), 1))
     if rank == world - 1:      # the last rank (the one with the ragged tail) reports
         q.put((res, ok_blob))

@@ -141,3 +141,66 @@ def test_concurrent_jobs_share_one_engine(monkeypatch, tmp_path):
     for tid in range(4):
         for i in range(len(imgs)):
             assert np.array_equal(results[tid][i], serial[i]), (tid, i)
+
+
+def test_concurrent_postprocess_jobs_share_one_handle():
+    """The app keeps ONE post-process handle per GPU (app.wow_sr._pp_engine) and the reference runs jobs
+    from concurrent worker threads (main.py:247-368, 629-675): 4 threads x different images of different
+    sizes through `_enhance_for_crops` / the farm functions must each get their own pixels back
+    (s2sr_postprocess_u8 holds the handle's lock from the upload to the download)."""
+    import threading
+    from app.farm_sr import apply_unsharp_mask
+    from app.wow_sr import _enhance_for_crops
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w) in [(96, 128), (200, 64), (128, 128), (333, 77)]]
+    for im in imgs:
+        im[..., 1] = np.maximum(im[..., 1], 80)
+    serial = [(_enhance_for_crops(im), apply_unsharp_mask(im, 1.2, 1.5)) for im in imgs]
+    for a, im in zip(serial, imgs):
+        assert np.array_equal(a[0], pp.enhance_for_crops(im))
+    errors = []
+    barrier = threading.Barrier(len(imgs))
+
+    def worker(i):
+        try:
+            barrier.wait(10)
+            for _ in range(25):
+                a = _enhance_for_crops(imgs[i])
+                b = apply_unsharp_mask(imgs[i], 1.2, 1.5)
+                if not (np.array_equal(a, serial[i][0]) and np.array_equal(b, serial[i][1])):
+                    errors.append(i)
+                    return
+        except Exception as e:                      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(imgs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errors, errors
+
+
+def test_http_enhance_upload_runs_on_gpu(monkeypatch, tmp_path):
+    """/api/enhance end to end (main.py:544-675): PNG upload -> admission -> anime model on the GPU ->
+    job table `completed` with the wow result schema."""
+    from fastapi.testclient import TestClient
+    from app.sr_routes import create_app
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    rgb = np.random.default_rng(8).integers(0, 256, (20, 28, 3), dtype=np.uint8)
+    png = tmp_path / "plate.png"
+    rio.write_png(png, rgb)
+    b = "BoUnD"
+    body = (f'--{b}\r\nContent-Disposition: form-data; name="model"\r\n\r\nrealesrgan_anime\r\n'
+            f'--{b}\r\nContent-Disposition: form-data; name="image"; filename="plate.png"\r\n'
+            f'Content-Type: image/png\r\n\r\n').encode() + png.read_bytes() + f"\r\n--{b}--\r\n".encode()
+    c = TestClient(create_app(tmp_path / "data", tiler=False, devices=[0]))
+    r = c.post("/api/enhance", content=body, headers={"content-type": f"multipart/form-data; boundary={b}"})
+    assert r.status_code == 200 and r.json()["model"] == "realesrgan_anime"
+    st = c.get(f"/api/sr/{r.json()['job_id']}").json()
+    assert st["status"] == "completed", st
+    out, _ = rio.read_rgb_u8(st["result"]["outputs"]["sr_png"])
+    exp = ref.enhance(np.ascontiguousarray(rgb[:, :, ::-1]), ref.to_torch_sd(synthetic_state_dict(6, seed=0)), 6)
+    exp = pp.enhance_for_crops(np.ascontiguousarray(exp[:, :, ::-1]))
+    d = np.abs(out.astype(np.int16) - exp.astype(np.int16))
+    assert out.shape == (80, 112, 3) and np.mean(d == 0) > 0.9

@@ -411,3 +411,117 @@ def test_subpixel_and_upsample_on_load_forms_agree(monkeypatch):
         print(f"precision {prec}: sub-pixel vs upsample-on-load max diff {d:.2e}")
         assert d <= (5e-5 if prec == native.PREC_F16_HP else 2e-3)
     monkeypatch.delenv("S2SR_NO_SUBPIXEL", raising=False)
+
+
+def _oracle_enhance_memo(img, sd, nb, tile, pad):
+    """oracle.enhance for large mosaics: same plan, same paste order, but windows the plan repeats (the
+    reference forwards identical rectangles again when a dimension ends within 2*pad of a tile multiple)
+    go through the CPU net once.  Identical inputs -> identical outputs, so the mosaic is unchanged."""
+    x = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    h, w = x.shape[2:]
+    assert h * w > tile * tile * 4
+    out = torch.zeros((1, 3, 4 * h, 4 * w))
+    memo = {}
+    with torch.no_grad():
+        for (y1, y2, x1, x2), (top, bottom, left, right), (oy1, oy2, ox1, ox2) in ref.tile_plan(h, w, tile, pad, 4):
+            if (y1, y2, x1, x2) not in memo:
+                memo[(y1, y2, x1, x2)] = ref.rrdbnet_forward(x[:, :, y1:y2, x1:x2], sd, nb, 4)
+            t = memo[(y1, y2, x1, x2)]
+            out[:, :, oy1:oy2, ox1:ox2] = t[:, :, top:t.shape[2] - bottom, left:t.shape[3] - right]
+    o = out.squeeze(0).permute(1, 2, 0).numpy()
+    return (o * 255.0).clip(0, 255).astype(np.uint8), o, len(memo)
+
+
+@pytest.mark.parametrize("H,W,tile,pad", [(1025, 1030, 512, 10), (1024, 1024, 256, 10)])
+def test_config2_aoi_mosaics_vs_oracle(H, W, tile, pad):
+    """BASELINE.json configs[2]: an AOI cut into overlapping windows -- (a) 512-px tiles (532x532 windows,
+    the edge windows shifted inward, duplicate rows/columns in the plan) on 1025x1030, (b) the reference's
+    own 256/10 plan on 1024x1024 (16 windows of 276x276) -- through the full-depth 6-block net
+    (realesrgan_anime shape) in HP mode against the oracle on this box's host cores."""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    nb = 6
+    img = np.random.default_rng(H * 7 + W).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    q_ref, f_ref, uniq = _oracle_enhance_memo(img, ref.to_torch_sd(synthetic_state_dict(nb, seed=0)), nb, tile, pad)
+    e = engine(nb, native.PREC_F16_HP)
+    f = e.enhance_f32(img, tile=tile, pad=pad)
+    err = float(np.abs(f - f_ref).max())
+    q = e.enhance_u8(img, tile=tile, pad=pad)
+    d = np.abs(q.astype(np.int16) - q_ref.astype(np.int16))
+    wins = native.plan_tiles(H, W, tile, pad, 4)
+    print(f"configs[2] {H}x{W} tile {tile}/{pad}: {len(wins)} windows ({uniq} distinct) of "
+          f"{wins[0].y2 - wins[0].y1}x{wins[0].x2 - wins[0].x1}, 6 blocks (hp): float err {err:.3e}, "
+          f"u8 identical {np.mean(d == 0):.4f}")
+    assert f.shape == (4 * H, 4 * W, 3) and q.shape == (4 * H, 4 * W, 3)
+    assert err <= TOL_HP and d.max() <= 1 and np.mean(d == 0) > 0.99
+
+
+def test_aoi_enhance_crops_composition_vs_oracles():
+    """configs[2] + configs[3] composed: SR mosaic (window plan) -> image-GLOBAL post-process (CLAHE's 8x8
+    grid spans the whole mosaic, wow_sr.py:191-192) against oracle(net) followed by oracle(post-process);
+    through app.wow_sr's own two steps and through s2sr.dist.enhance_distributed(enhance_crops=...)."""
+    import os
+    import torch.distributed as dist
+    from oracle import postprocess_ref as pp
+    from s2sr.dist import NativeBackend, enhance_distributed
+    nb, tile, pad = 6, 64, 10
+    H, W = 150, 170                      # 3x3 windows of 84x84, shifted edges
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    rgb[..., 1] = np.maximum(rgb[..., 1], 90)      # green-dominant: exercises the hue 36..84 branch
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    sd = ref.to_torch_sd(synthetic_state_dict(nb, seed=0))
+    sr_ref = ref.enhance(bgr, sd, nb, tile_size=tile, tile_pad=pad)
+    e = engine(nb, native.PREC_F16_HP)
+    sr = e.enhance_u8(bgr, tile=tile, pad=pad)
+    assert np.abs(sr.astype(np.int16) - sr_ref.astype(np.int16)).max() <= 1
+    # the post-process is bit-exact against its oracle on the SAME input; composed, the <=1-LSB differences
+    # of the net output pass through CLAHE/unsharp (gain up to ~2.2 + LUT steps), so compare stage-wise
+    # exactly and end-to-end loosely
+    got = e.postprocess_u8(np.ascontiguousarray(sr[:, :, ::-1]), native.pp_wow())
+    assert np.array_equal(got, pp.enhance_for_crops(np.ascontiguousarray(sr[:, :, ::-1])))
+    end_ref = pp.enhance_for_crops(np.ascontiguousarray(sr_ref[:, :, ::-1]))
+    d = np.abs(got.astype(np.int16) - end_ref.astype(np.int16))
+    print(f"AOI {H}x{W} SR+post-process vs oracle.oracle: max |d| {d.max()}, identical {np.mean(d == 0):.4f}")
+    assert d.max() <= 12 and np.mean(d == 0) > 0.97
+    # the distributed composition (one rank; RCCL) gives the same bytes as the two steps above
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        be = NativeBackend(e, 0)
+        for dst in (None, 0):
+            out = enhance_distributed(be, bgr, tile, pad, dst=dst, enhance_crops=native.pp_wow())
+            assert np.array_equal(out[:, :, ::-1], got), dst
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_path():
+    """The RCCL leg of the multi-GPU path executed for real (backend "nccl" == RCCL, one rank): process-group
+    init, weight broadcast from a device tensor into s2sr_load_weights_dev, all-gather and gather of
+    device-resident u8 window outputs, stitch.  N > 1 needs a multi-GPU node (driver's SCALE run)."""
+    import os
+    import torch.distributed as dist
+    from s2sr.dist import NativeBackend, enhance_distributed, forward_batch_distributed, load_broadcast_weights
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        nb = 2
+        e = native.Engine(num_block=nb, precision=native.PREC_F16_HP)
+        load_broadcast_weights(e, synthetic_state_dict(nb, seed=0), nb, dev)
+        ref_e = engine(nb, native.PREC_F16_HP)                     # same weights through the host entry
+        be = NativeBackend(e, 0)
+        rng = np.random.default_rng(41)
+        img = rng.integers(0, 256, size=(70, 90, 3), dtype=np.uint8)
+        exp = ref_e.enhance_u8(img, tile=32, pad=4)
+        assert np.array_equal(enhance_distributed(be, img, 32, 4), exp)
+        assert np.array_equal(enhance_distributed(be, img, 32, 4, dst=0), exp)
+        tiles = rng.integers(0, 256, size=(5, 24, 40, 3), dtype=np.uint8)
+        assert np.array_equal(forward_batch_distributed(be, tiles), ref_e.forward_batch_u8(tiles))
+        e.close()
+    finally:
+        dist.destroy_process_group()

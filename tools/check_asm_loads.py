@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Static check of the conv kernels' hidden (inline-asm) global loads.
+
+The epilogue's residual loads are inline asm so that hipcc's waitcnt pass does not drain the LDS-DMA
+ring (conv3x3.hip, asm_load16).  The price: the compiler does not know their destination registers are
+in flight.  This script reads the device assembly and reports every instruction that touches a
+destination register of such a load between the load and the next `s_waitcnt vmcnt(0)` -- the pattern
+behind r01's fault in the 4-wave variant (a copy of a not-yet-arrived register, then reuse of the
+register as an address).
+
+    hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -S --cuda-device-only conv3x3.hip -o conv.s
+    tools/check_asm_loads.py conv.s
+"""
+import re
+import sys
+
+
+def regs(tok):
+    m = re.fullmatch(r"([av])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {f"{m.group(1)}{i}" for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.fullmatch(r"([av])(\d+)", tok)
+    return {f"{m.group(1)}{m.group(2)}"} if m else set()
+
+
+def check(path):
+    bad = 0
+    kernel = None
+    pending = {}          # reg -> line number of the load
+    in_asm = False
+    for ln, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.endswith(":") and t.startswith("_Z"):
+            kernel, pending = t[:-1], {}
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        toks = re.findall(r"[av]\[\d+:\d+\]|[av]\d+", t)
+        if in_asm and t.startswith("global_load_dword") and "lds" not in t:
+            dst = regs(toks[0]) if toks else set()
+            for r in dst:
+                pending[r] = ln
+            continue
+        if "s_waitcnt" in t and re.search(r"vmcnt\(0\)", t):
+            pending = {}
+            continue
+        if pending:
+            used = set()
+            for tok in toks:
+                used |= regs(tok)
+            hit = used & set(pending)
+            if hit:
+                bad += 1
+                print(f"{path}:{ln}: {kernel}: `{t}` touches {sorted(hit)} loaded at line {min(pending[r] for r in hit)} before vmcnt(0)")
+    return bad
+
+
+if __name__ == "__main__":
+    n = sum(check(p) for p in sys.argv[1:])
+    print(f"{n} hazard(s)")
+    sys.exit(1 if n else 0)
