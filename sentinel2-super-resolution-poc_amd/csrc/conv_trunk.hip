@@ -1,0 +1,525 @@
+// The 345 convs of the RRDB trunk (ResidualDenseBlock conv1..5, reference
+// server/app/cnn_super_resolution.py:85-91; RRDB :103-107) as ONE-WAVE-PER-SIMD workgroups.
+//
+// Same GEMM orientation, HBM layout, LDS-DMA ring and epilogue arithmetic as conv3x3.hip (read its
+// header first); what changes is who issues the MFMAs and how the stream around them is laid out:
+//
+//   * 4 waves per workgroup, one per SIMD, 512 registers each: the accumulators (8 rows x 32 couts or
+//     4 rows x 64 couts per wave = 128 registers) live in AGPRs for the whole patch, the MFMAs are
+//     inline asm with "+a" operands.  (With the builtin hipcc moves every finished accumulator
+//     AGPR -> VGPR -> AGPR once per stage, ~7 v_accvgpr moves per MFMA: 51-67 cycles per MFMA instead
+//     of 32.)  Two MFMA-bound waves on one SIMD do not add up either: measured in the 8-wave form the
+//     older wave issues at 57 cycles per MFMA and the younger mostly waits for it (46 per MFMA for
+//     the pair, profiles/r02_wave_anatomy.txt) -- an in-order wave cannot use an MFMA-pipe gap
+//     shorter than one MFMA.
+//   * the K loop of a stage walks dx -> slab row -> dy, so a B fragment (slab row, column shift) is read
+//     once and feeds the three kernel rows; B fragments are requested three steps ahead, the A
+//     fragments of a kernel column one column ahead (9*CT fragment registers).
+//   * the workgroup barrier sits THREE STEPS BEFORE THE END of a stage: behind it the wave first
+//     requests the next stage's first fragments (other ring slot), then issues the 6*CT MFMAs it still
+//     owes the current stage -- LDS latency and barrier skew hide under them.  The barrier is at the
+//     same time the release of the current slot (every read of it has been issued before, and
+//     lgkmcnt(0) in the same statement completes them), so the refill DMA of that slot starts with
+//     the next stage.
+//   * every stage issues exactly PW LDS-DMA instructions per wave, unconditionally (at the end of a
+//     workgroup's work the cursor stays on its last stage: two redundant stage loads per launch), so
+//     the loop has no branches around DMA and every vmcnt is a compile-time constant.
+//   * the slab swizzle is keyed on the COLUMN's bit 3 (not the pixel index's): conflict-free for
+//     ds_read_b128 all the same, and it makes every fragment address "per-lane base + immediate".
+//   * the first MFMA of an accumulator in a patch takes C = 0, the bias is added in the epilogue
+//     (no 128 v_accvgpr_write per patch).
+#include <math.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <type_traits>
+
+#include "s2sr_internal.h"
+
+namespace s2sr {
+
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CT_, int NP_, int R_>
+struct TG {
+    static constexpr int CT = CT_, NP = NP_, R = R_, WAVES = 4;
+    static constexpr int TH = WAVES * NP, TW = 32, SW = TW + 2, SH = TH + 2, SPX = SH * SW;
+    static constexpr int ROWB = SW * 32;                       // bytes of one slab row
+    static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
+    static constexpr int PI = PLANE / 1024, WI = 9 * CT, NSTI = PI + WI;
+    static constexpr int PW = (NSTI + WAVES - 1) / WAVES;      // LDS-DMA instructions per wave and stage
+    static constexpr int STAGE_BYTES = NSTI * 1024;
+    static constexpr int RING_BYTES = R * STAGE_BYTES;
+    static constexpr int BIAS_OFF = RING_BYTES;
+    static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
+    static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per stage
+    static constexpr int NW = PW * (R - 2);                    // DMA instructions that may stay in flight at a barrier
+    static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
+    static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
+    static_assert(PW <= T - 3, "DMA slots must fit in front of the barrier step");
+};
+
+// LDS-DMA, 16 B per lane (conv3x3.hip glds16).  FORCE_UNIFORM: the stamped diagnostic build's divergent stamp
+// branches make hipcc keep the uniform base / LDS address in VGPRs; re-derive them through v_readfirstlane.
+template <bool FORCE_UNIFORM>
+__device__ __forceinline__ void glds16(const char* base, uint32_t voff, uint32_t lds_addr) {
+    if (FORCE_UNIFORM) {
+        const uint64_t v = (uint64_t)base;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        base = (const char*)(((uint64_t)hi << 32) | lo);
+        lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
+    } else {
+        // the slot offset also feeds VALU address arithmetic, and hipcc then keeps it in a VGPR, which an "s"
+        // operand does not legalise: pin it to an SGPR (folds away when it already is one)
+        lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
+    }
+}
+// hidden global loads into AGPRs + landing tie: see conv3x3.hip (asm_load16)
+__device__ __forceinline__ f32x4 asm_load16(const char* addr) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x2 asm_load8(const char* addr) {
+    u32x2 r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(r) : "v"(addr) : "memory");
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ void asm_land(T& r) { asm volatile("" : "+a"(r)); }
+
+__device__ __forceinline__ f32x4 half4_to_float(u32x2 h) {
+    const f16x4 v = __builtin_bit_cast(f16x4, h);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
+    return o;
+}
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0.2f)); }
+
+// acc (AGPRs) += A x B, or = A x B for the first MFMA of a patch
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_release_barrier() {
+    // my DMA pieces of the awaited stage have landed (all but the N youngest vector-memory ops are done),
+    // my LDS reads of the slot being released have returned; past the barrier both hold for every wave
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int EPI, int CT, int NP>
+struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3x3.hip EpiStores)
+    static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : (EPI == EPI_RDB5) ? CT * 4 * NP : CT * 8 * NP;
+};
+
+template <int CT, int NP, int R, int EPI, bool TRACE>
+__global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
+    using G = TG<CT, NP, R>;
+    constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
+    static_assert(EPI == EPI_LRELU || kTrunk, "trunk kernel: conv1-4 (LRELU) and conv5 (RDB5 / RDB5_RRDB) only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pcol = lane & 31, hh = lane >> 5;
+
+    // ---- my patches (XCD-aware round-robin, as in conv3x3.hip)
+    const int nwg = gridDim.x;
+    const int slot_in_round = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+    const int tpi = p.tilesX * p.tilesY;
+    const int ntiles = tpi * p.N;
+    const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;
+    if (my_tiles <= 0) return;                                   // workgroup-uniform
+    const int NS = p.nstage;
+    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {          // whole-kernel clock stamps (tools/trunk_anatomy.py)
+        p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
+    }
+    const uint32_t sblk = (uint32_t)p.sHp * p.sWp * 32;
+    const size_t oblk = (size_t)p.Hp * p.Wp * 32;
+
+    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
+
+    // ---- per-lane global offsets of this wave's PW DMA pieces (patch independent)
+    uint32_t loff[G::PW];
+#pragma unroll
+    for (int sl = 0; sl < G::PW; ++sl) {
+        int j = wave + sl * 4;
+        if (j > G::NSTI - 1) j = G::NSTI - 1;                    // padding slot: the last piece again
+        if (j < G::PI) {
+            const int i = j * 64 + lane;                         // 16-B piece of the slab plane in LDS order
+            int q = i >> 1;
+            if (q >= G::SPX) q = 0;                              // tail pieces land in the plane's pad
+            const int ry = q / G::SW, rx = q - ry * G::SW;
+            const int h2 = (i & 1) ^ ((rx >> 3) & 1);            // swizzle on bit 3 of the COLUMN
+            loff[sl] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
+        } else {
+            loff[sl] = (uint32_t)((j - G::PI) * 1024 + lane * 16);
+        }
+    }
+
+    // ---- DMA issue cursor: (tile iteration, stage in patch); stays on the very last stage once it gets there
+    int it_i = 0, st_i = 0;
+    const char* pbase = nullptr;
+    const char* sb_i = nullptr;          // slab source of the stage under the cursor
+    const char* wb_i = nullptr;          // its weights
+    auto cursor_next = [&]() __attribute__((always_inline)) {
+        if (st_i == 0) {
+            const int tile = it_i * nwg + slot_in_round;
+            const int n = tile / tpi;
+            const int trem = tile - n * tpi;
+            const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+            pbase = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
+        }
+        sb_i = pbase + (size_t)st_i * sblk;
+        wb_i = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
+        if (++st_i == NS) {
+            if (it_i + 1 < my_tiles) { st_i = 0; ++it_i; }
+            else st_i = NS - 1;                                   // clamp: re-load the last stage (into a free slot)
+        }
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    auto dma_piece = [&](int sl, uint32_t slot_off) __attribute__((always_inline)) {
+        int j = wave + sl * 4;
+        if (j > G::NSTI - 1) j = G::NSTI - 1;
+        if (TRACE && (p.dbg & 8)) return;                         // ablation (results wrong): no DMA instruction at all
+        glds16<TRACE>(j < G::PI ? sb_i : wb_i, loff[sl], lds0 + slot_off + (uint32_t)j * 1024);
+    };
+
+    // ---- fragment addresses inside a slot: per-lane base + immediate
+    uint32_t bbase[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int c = pcol + dx;
+        bbase[dx] = (uint32_t)((wave * NP) * G::ROWB + c * 32 + 16 * (hh ^ ((c >> 3) & 1)));
+    }
+    const uint32_t abase = (uint32_t)(G::PLANE + lane * 16);
+    // conv5: x of the patch's own pixels (channels 8g+4hh.. of block r) is picked out of the slab while stages 0..3 are in LDS
+    const uint32_t cbase = (uint32_t)((wave * NP + 1) * G::ROWB + (pcol + 1) * 32 + 8 * hh + 16 * (((pcol + 1) >> 3) & 1));
+    u32x2 hi_cap[kTrunk ? 4 : 1][kTrunk ? NP : 1][2];
+
+    char* const trash = p.trash + (size_t)tid * 16;
+
+    f32x16 acc[CT][NP];
+    f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
+    f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
+
+    // ---- prologue: R-1 stages in flight, then the first fragments of stage 0
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) {
+        cursor_next();
+#pragma unroll
+        for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, (uint32_t)(r * G::STAGE_BYTES));
+    }
+    uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
+    wait_release_barrier<G::NW>();                                // stage 0 has landed (and the bias is visible)
+    {
+        const char* sb = smem;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3) * CT + ct) * 1024);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) breg[v] = *(const f16x8*)(sb + bbase[0] + v * G::ROWB);
+    }
+
+    int kglob = 0;   // TRACE only
+
+    // One stage.  FIRST: first stage of a patch (accumulators start from C = 0; the barrier inside it may also
+    // leave the previous patch's epilogue stores in flight).  CAP >= 0: capture x block CAP for the trunk epilogue.
+    auto stage = [&](auto first_tag, auto cap_tag, bool first_patch) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int CAP = decltype(cap_tag)::value;
+        const uint32_t next_off = (cur_off + G::STAGE_BYTES == (uint32_t)G::RING_BYTES) ? 0u : cur_off + G::STAGE_BYTES;
+        const uint32_t dma_off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
+        const char* sb = smem + cur_off;
+        const char* sn = smem + next_off;
+        cursor_next();                                            // the stage R-1 ahead: its DMA rides on this stage
+#pragma unroll
+        for (int t = 0; t < G::T; ++t) {
+            const int dx = t / (NP + 2), s = t % (NP + 2);
+            if (t == G::T - 3) {
+                // next stage landed + this slot released; everything below reads the NEXT slot
+                constexpr int NST = TrunkStores<EPI, CT, NP>::value;
+                constexpr int NEPI = (G::NW + NST < 63) ? G::NW + NST : 63;
+                if (FIRST && !first_patch) wait_release_barrier<NEPI>();
+                else wait_release_barrier<G::NW>();
+                if (TRACE && p.trace && (p.dbg & 4) && lane == 0) {
+                    if (kglob == 4) p.trace[(size_t)blockIdx.x * 24 + 0 * 8 + wave] = __builtin_amdgcn_s_memtime();
+                    if (kglob == 5) p.trace[(size_t)blockIdx.x * 24 + 1 * 8 + wave] = __builtin_amdgcn_s_memtime();
+                }
+            }
+            // B fragment of step t+3
+            {
+                const int u = t + 3;
+                if (u < G::T) breg[u % 6] = *(const f16x8*)(sb + bbase[u / (NP + 2)] + (u % (NP + 2)) * G::ROWB);
+                else breg[u % 6] = *(const f16x8*)(sn + bbase[0] + (u - G::T) * G::ROWB);
+            }
+            // A fragments: the next kernel column's, one per step; behind the barrier the next stage's column 0
+            if (dx < 2 && s < 3 * CT) {
+                const int f = s, dy = f / CT, ct = f % CT;
+                acol[dx + 1][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3 + dx + 1) * CT + ct) * 1024);
+            }
+            if (t >= G::T - 3) {
+                const int dy = t - (G::T - 3);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sn + abase + ((dy * 3) * CT + ct) * 1024);
+            }
+            if (kTrunk && CAP >= 0 && t >= 1 && t <= 2 * NP) {
+                const int np = (t - 1) >> 1, half = (t - 1) & 1;
+                hi_cap[CAP < 0 ? 0 : CAP][np][half] = *(const u32x2*)(sb + (cbase ^ (half * 16)) + np * G::ROWB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
+#pragma unroll
+            for (int sl = 0; sl < G::PW; ++sl)
+                if ((sl * (G::T - 3)) / G::PW == t) dma_piece(sl, dma_off);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int np = s - dy;
+                if (np < 0 || np >= NP) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (FIRST && dx == 0 && dy == 0) mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                    else mfma_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (TRACE && p.trace && (p.dbg & 4) && lane == 0 && kglob == 5)
+            p.trace[(size_t)blockIdx.x * 24 + 2 * 8 + wave] = __builtin_amdgcn_s_memtime();
+        if (TRACE) ++kglob;
+        cur_off = next_off;
+    };
+
+    // ---- epilogue of the patch at tile iteration `it` (arithmetic as in conv3x3.hip; the bias joins here)
+    auto epilogue = [&](int it) __attribute__((always_inline)) {
+        // the MFMA results must have left the matrix pipe before the VALU reads them; hipcc does not know these
+        // asm statements are MFMAs, so the wait states are spelled out (16-pass MFMA: 18 needed)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        const int tile = it * nwg + slot_in_round;
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+        const int y0 = ty * G::TH, x0 = tx * G::TW;
+        const int x = x0 + pcol;
+        f32x16 bv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *(const f32x4*)(smem + G::BIAS_OFF + (ct * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = v[i];
+            }
+        bool ok[NP];
+        size_t opix[NP];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const int y = y0 + wave * NP + np;
+            ok[np] = (y < p.H) && (x < p.W);
+            opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
+        }
+        const size_t tn = (size_t)n * 8 * oblk;   // image offset inside an fp32 skip tensor (R), bytes
+        const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensor, bytes
+        u32x2 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
+        f32x4 res1[EPI == EPI_RDB5_RRDB ? CT : 1][4];
+        auto load_lo = [&](int np) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
+                        asm_load8((const char*)p.T + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
+        };
+        if (kTrunk) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np) load_lo(np);
+            if (EPI == EPI_RDB5) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) asm_land(lo_old[ct][np][g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            if (EPI == EPI_RDB5_RRDB) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        res1[ct][g] = asm_load16((const char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        asm_land(res1[ct][g]);
+                        if (np == 0) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) asm_land(lo_old[ct][q][g]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                u32x2 hpk[4], lpk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
+                    if (EPI == EPI_LRELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                    } else {
+                        // t = hi + lo (exact in fp32); hi was captured from LDS: block ct*2 + (g>>1), half g&1
+                        const f32x4 th = half4_to_float(hi_cap[kTrunk ? (ct * 2 + (g >> 1)) & 3 : 0][kTrunk ? np : 0][g & 1]);
+                        const f32x4 tl = half4_to_float(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float t = __fadd_rn(th[i], tl[i]);
+                            v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), t);
+                            if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res1[EPI == EPI_RDB5_RRDB ? ct : 0][g][i]);
+                        }
+                        if (EPI == EPI_RDB5_RRDB)
+                            *(f32x4*)(ok[np] ? (char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16 : trash) = v;
+                    }
+                    f16x4 hv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
+                    hpk[g] = __builtin_bit_cast(u32x2, hv);
+                    if (kTrunk) {
+                        f16x4 lv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) lv[i] = (f16)__fsub_rn(v[i], (float)hv[i]);
+                        lpk[g] = __builtin_bit_cast(u32x2, lv);
+                    }
+                }
+                // pair the half-waves: one 16-B store per 16-channel block, 1 KiB contiguous per wave-instruction
+#pragma unroll
+                for (int bk = 0; bk < 2; ++bk) {
+                    u32x2 lo = hpk[2 * bk], hi = hpk[2 * bk + 1];
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+                    u32x4 o;
+                    o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
+                    *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
+                    if (kTrunk) {
+                        u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
+                        const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
+                        const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
+                        u32x4 ol;
+                        ol[0] = q0[0]; ol[1] = q1[0]; ol[2] = q0[1]; ol[3] = q1[1];
+                        *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = ol;
+                    }
+                }
+            }
+        }
+    };
+
+    using std::integral_constant;
+    for (int it = 0; it < my_tiles; ++it) {
+        const bool first_patch = it == 0;
+        if (kTrunk) {   // NS >= 4 (host): stages 0..3 are the 64 channels of x
+            stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 3>{}, false);
+            for (int st = 4; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+        } else {
+            stage(integral_constant<bool, true>{}, integral_constant<int, -1>{}, first_patch);
+            for (int st = 1; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+        }
+        epilogue(it);
+    }
+    // nothing may still be on its way into this workgroup's LDS when it ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {
+        p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+template <int CT, int NP, int R, int EPI, bool TRACE>
+hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
+    using G = TG<CT, NP, R>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
+    static_assert(G::NW < 64, "vmcnt field is 6 bits");
+    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE>;
+    static std::mutex attr_mu;
+    static bool attr_set[64] = {false};
+    static int ncu_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int ncu;
+    {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            int n = 256;
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            ncu_dev[dev] = n;
+            attr_set[dev] = true;
+        }
+        ncu = ncu_dev[dev];
+    }
+    // operand shapes the kernel's indexing assumes (a violation would read or write outside the tensors)
+    if (p.nstage < 1 || p.nstage > 12 || p.sHp != p.Hp || p.sWp != p.Wp || p.Hp < p.H + 2 || p.Wp < p.W + 2) return hipErrorInvalidValue;
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 4 || !p.T || (EPI == EPI_RDB5_RRDB && !p.R))) return hipErrorInvalidValue;
+    if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;   // slabs of edge patches stay inside the plane
+    if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash) return hipErrorInvalidValue;
+    ConvParams q = p;
+    q.tilesX = (p.W + G::TW - 1) / G::TW;
+    q.tilesY = (p.H + G::TH - 1) / G::TH;
+    const int ntiles = q.tilesX * q.tilesY * p.N;
+    int grid = ncu & ~7;
+    if (ntiles < grid) grid = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// ct = 1: conv1..4 (EPI_LRELU); ct = 2: conv5 (EPI_RDB5 / EPI_RDB5_RRDB).  Returns hipErrorNotSupported for
+// anything else.
+hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace) {
+    if (ct == 1 && epi == EPI_LRELU) {
+        // 32x32 patches (8 rows per wave, 3-deep ring) unless that leaves most CUs without a patch (single tiles):
+        // then 16x32 patches (4 rows per wave, 5-deep ring) spread the image over twice as many workgroups.  Both
+        // forms accumulate in the same order, so the result does not depend on the choice.
+        const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
+        if (n32 < 192 && !trace) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
+        return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
+    }
+    if (ct == 2 && epi == EPI_RDB5) return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);
+    if (ct == 2 && epi == EPI_RDB5_RRDB) return launch_trunk_t<2, 4, 4, EPI_RDB5_RRDB, false>(p, st);
+    return hipErrorNotSupported;
+}
+
+}  // namespace s2sr

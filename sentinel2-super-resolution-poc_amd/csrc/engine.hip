@@ -97,6 +97,7 @@ struct s2sr_handle {
     hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
     std::vector<hipEvent_t> group_done;
     // hipGraph replay of repeated groups
+    bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
@@ -266,6 +267,11 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
+    if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
+        const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
+        if (e == hipSuccess) return S2SR_OK;
+        if (e != hipErrorNotSupported) HIPCHK(h, e);
+    }
     HIPCHK(h, launch_conv(p, cw.ct, epi, up, lo_out, st, cw.f8));
     return S2SR_OK;
 }
@@ -504,6 +510,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
         return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
     }
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
@@ -1203,10 +1210,16 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
         HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)256 * 24 * 8));
         p.trace = d_tr;
     }
-    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_conv(p, ct, epi, false, false, st));
+    auto launch_one = [&](bool tr) -> hipError_t {
+        if (h->trunk_w4) {
+            const hipError_t e = launch_conv_trunk(p, ct, epi, st, tr);
+            if (e != hipErrorNotSupported) return e;
+        }
+        return tr ? launch_conv_trace(p, ct, st) : launch_conv(p, ct, epi, false, false, st);
+    };
+    for (int i = 0; i < 3; ++i) HIPCHK(h, launch_one(false));
     HIPCHK(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i)
-        HIPCHK(h, timed_trace ? launch_conv_trace(p, ct, st) : launch_conv(p, ct, epi, false, false, st));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_one(timed_trace));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms = 0;
@@ -1217,7 +1230,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
         if (!d_tr) HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
         HIPCHK(h, hipMemset(d_tr, 0, (size_t)nwg * 24 * 8));
         p.trace = d_tr;
-        HIPCHK(h, launch_conv_trace(p, ct, st));
+        HIPCHK(h, launch_one(true));
         HIPCHK(h, hipStreamSynchronize(st));
         const int nw = trace_wgs < nwg ? trace_wgs : nwg;
         HIPCHK(h, hipMemcpy(trace, d_tr, (size_t)nw * 24 * 8, hipMemcpyDeviceToHost));

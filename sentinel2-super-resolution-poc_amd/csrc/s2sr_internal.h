@@ -80,6 +80,9 @@ struct ConvParams {
 // conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.
 hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool lo_out, hipStream_t st, bool f8_in = false);
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
+// the RRDB trunk convs as one-wave-per-SIMD workgroups (conv_trunk.hip): ct 1 + EPI_LRELU (conv1..4), ct 2 + EPI_RDB5 /
+// EPI_RDB5_RRDB (conv5).  hipErrorNotSupported = not a trunk form / launch too small: use launch_conv.
+hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace = false);
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
 // nseg 1: [w_hi]; 2: [w_hi][w_lo] (exact-integer inputs: conv_first); 3: [w_hi][w_hi][w_lo]

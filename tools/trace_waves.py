@@ -12,10 +12,11 @@ for cin, cout in ((64, 32), (160, 32), (192, 64)):
     us, tr = e.bench_conv(8, 256, 256, cin, cout, iters=5, trace_wgs=256)
     tr = tr.astype(np.int64)
     tr = tr[tr[:, 0] > 0]
-    leave5, leave6, end5 = tr[:, 0:8], tr[:, 8:16], tr[:, 16:24]
+    nw = 8 if (tr[:, 4:8] > 0).any() else 4          # 8-wave kernel or the one-wave-per-SIMD trunk kernel
+    leave5, leave6, end5 = tr[:, 0:nw], tr[:, 8:8 + nw], tr[:, 16:16 + nw]
     t0 = leave5.min(axis=1, keepdims=True)
     print(f"cin={cin} cout={cout}: stage 5, cycles relative to first wave leaving the barrier (median over {len(tr)} WGs)")
-    print("   wave:            " + " ".join(f"{w:6d}" for w in range(8)))
-    print("   leave barrier 5: " + " ".join(f"{int(np.median(leave5[:, w] - t0[:, 0])):6d}" for w in range(8)))
-    print("   last MFMA issued:" + " ".join(f"{int(np.median(end5[:, w] - t0[:, 0])):6d}" for w in range(8)))
-    print("   leave barrier 6: " + " ".join(f"{int(np.median(leave6[:, w] - t0[:, 0])):6d}" for w in range(8)))
+    print("   wave:            " + " ".join(f"{w:6d}" for w in range(nw)))
+    print("   leave barrier 5: " + " ".join(f"{int(np.median(leave5[:, w] - t0[:, 0])):6d}" for w in range(nw)))
+    print("   last MFMA issued:" + " ".join(f"{int(np.median(end5[:, w] - t0[:, 0])):6d}" for w in range(nw)))
+    print("   leave barrier 6: " + " ".join(f"{int(np.median(leave6[:, w] - t0[:, 0])):6d}" for w in range(nw)))
