@@ -40,6 +40,11 @@ extern "C" {
                             * hr, last) computed with split fp16 operands (x_hi,w_hi)+(x_lo,w_hi)+(x_hi,w_lo):
                             * fp32-class head/tail, ~1e-4 of the fp32 reference at ~1.2x the time            */
 
+#define S2SR_PREC_FP8 2    /* the 345 RDB convs on e4m3 operands (block-scaled fp8 MFMA, K = 64; per-output-channel weight
+                            * scales, per-tensor-kind activation scales, fp16 trunk); head / tail convs as in F16_HP.
+                            * BASELINE.json configs[4] (the /api/sr variant).  NOT within the 1e-3 tolerance: e4m3 keeps
+                            * 3 mantissa bits; measured max-abs in tests/test_gpu_net.py (test_fp8_mode_*)             */
+
 typedef struct s2sr_handle s2sr_handle;
 
 /* Mirrors the constructor arguments of the reference net

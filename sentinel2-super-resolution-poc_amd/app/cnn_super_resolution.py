@@ -113,11 +113,12 @@ class RRDBNet(nn.Module):
 
     def engine(self, device_index: int = 0) -> native.Engine:
         ver = self._version()
-        if self._engine is not None and self._engine_key is not None and self._engine_key[1:] == (device_index, ver):
+        prec = _precision_override() or os.environ.get("S2SR_PRECISION", "hp")
+        if self._engine is not None and self._engine_key is not None and self._engine_key[1:] == (device_index, ver, prec):
             return self._engine
         fp = self._fingerprint()
         self._engine = _engine_for(self.state_dict(), self.num_block, device_index, fp)
-        self._engine_key = (fp, device_index, ver)
+        self._engine_key = (fp, device_index, ver, prec)
         return self._engine
 
     @torch.no_grad()
@@ -138,11 +139,13 @@ _MODELS_LOCK = threading.Lock()
 def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str) -> native.Engine:
     """One native handle per (weights, GPU), shared by every RealESRGAN object of the process."""
     with _ENGINES_LOCK:
-        key = (fingerprint, device_index)
+        key = (fingerprint, device_index, _precision_override() or os.environ.get("S2SR_PRECISION", "hp"))
         eng = _ENGINES.get(key)
         if eng is None:
-            # S2SR_PRECISION=fast trades the <=1e-4 parity of the default for ~14 % more throughput
-            prec = native.PREC_F16 if os.environ.get("S2SR_PRECISION", "hp") == "fast" else native.PREC_F16_HP
+            # S2SR_PRECISION=fast trades the <=1e-4 parity of the default for ~14 % more throughput; =fp8 runs the RDB
+            # trunk on e4m3 operands (BASELINE configs[4], ~1.5x, max-abs ~5e-3: outside the 1e-3 tolerance)
+            prec = {"fast": native.PREC_F16, "fp8": native.PREC_FP8}.get(_precision_override() or
+                                                                          os.environ.get("S2SR_PRECISION", "hp"), native.PREC_F16_HP)
             eng = native.Engine(num_block=num_block, device=device_index, precision=prec,
                                 group=int(os.environ.get("S2SR_GROUP", "0")))
             eng.load_blob(flatten_state_dict(state_dict, num_block))
@@ -151,6 +154,27 @@ def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str)
 
 
 _THREAD = threading.local()
+
+
+class thread_precision:
+    """`with thread_precision("fp8"):` -- engines built for jobs on this thread use that arithmetic
+    (app.farm_sr selects the /api/sr path onto the fp8 trunk with S2SR_FARM_PRECISION=fp8)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_THREAD, "precision", None)
+        _THREAD.precision = self.name
+        return self
+
+    def __exit__(self, *exc):
+        _THREAD.precision = self.prev
+        return False
+
+
+def _precision_override():
+    return getattr(_THREAD, "precision", None)
 
 
 class thread_device:

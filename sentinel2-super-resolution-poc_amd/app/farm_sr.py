@@ -43,8 +43,12 @@ def apply_farm_sr(input_path: Path, output_path: Path, scale: int = 4) -> Tuple[
     img, georef = rio.read_rgb_u8(input_path)
     original_shape = img.shape[:2]
     # scale 2|3 -> model name "realesrgan_x2|3" is not in MODELS -> ValueError, as in the reference (:162)
-    esrgan = RealESRGAN(scale=scale, tile_size=256)
-    sr_rgb = np.ascontiguousarray(esrgan.enhance(np.ascontiguousarray(img[:, :, ::-1]))[:, :, ::-1])
+    # S2SR_FARM_PRECISION=fp8 puts the /api/sr path on the fp8 (e4m3) trunk -- BASELINE.json configs[4]; default: as /api/wow
+    import os
+    from app.cnn_super_resolution import thread_precision
+    with thread_precision(os.environ.get("S2SR_FARM_PRECISION") or None):
+        esrgan = RealESRGAN(scale=scale, tile_size=256)
+        sr_rgb = np.ascontiguousarray(esrgan.enhance(np.ascontiguousarray(img[:, :, ::-1]))[:, :, ::-1])
     final = _pp_engine().postprocess_u8(sr_rgb, native.pp_farm())    # the three steps of :170-178 fused
 
     output_path = Path(output_path)

@@ -504,6 +504,452 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+// ==========================================================================================
+// fp8 trunk (S2SR_PREC_FP8): the same convs on e4m3 operands with the block-scaled MFMA
+// v_mfma_scale_f32_32x32x64_f8f6f4 -- K = 64 per instruction = two planes of 32 channels (lanes 0-31
+// take their 32 K bytes from plane A, lanes 32-63 from plane B), 64 cycles per MFMA, twice the fp16
+// rate on half the bytes.  A 64-cycle MFMA also covers the ~60 cycles an LDS-DMA instruction holds the
+// wave's issue port, which the one-wave-per-SIMD form cannot hide behind 32-cycle fp16 MFMAs.
+//   * a PAIR-STEP consumes two planes.  LDS: a ring of RS slab slots (one plane each) + a 2-slot ring of
+//     weight blocks (the two planes' 9*CT KiB each): slabs arrive RS/2-1 pair-steps ahead, the L2-hot
+//     weights one pair-step ahead, weights issued first (vmcnt completes in issue order).
+//   * the MFMA's hardware scales do the dequantisation: scale_a (per lane = per cout row) carries the
+//     per-output-channel weight scale 2^-k_co, scale_b the activation scale 2^-x_exp / 2^-g_exp.
+//   * both 16-B halves of a pixel are needed by the same lane, so the two ds_read_b128 of a B fragment
+//     fetch "logical half 0" and "logical half 1" (different physical halves for swizzled columns):
+//     conflict-free, and the bytes arrive in channel order without a select.
+//   * odd plane counts (Cin 96, 160) are padded with a phantom plane: plane 0 again, against zero weights.
+//   * the trunk itself stays fp16 (xh_in / xh_skip / xh_out): the e4m3 rounding of the conv operands
+//     (2^-4 relative) dominates everything a second fp16 "lo" half could add.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma8_acc(f32x16& acc, const v8i& a, const v8i& b, int sa, int sb) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+__device__ __forceinline__ void mfma8_first(f32x16& acc, const v8i& a, const v8i& b, int sa, int sb) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
+template <int CT_, int NP_, int RS_>
+struct TG8 {
+    static constexpr int CT = CT_, NP = NP_, RS = RS_, WAVES = 4;
+    static constexpr int TH = WAVES * NP, TW = 32, SW = TW + 2, SH = TH + 2, SPX = SH * SW;
+    static constexpr int ROWB = SW * 32;
+    static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
+    static constexpr int PI = PLANE / 1024;                     // slab DMA pieces per plane
+    static constexpr int WI = 9 * CT;                           // weight DMA pieces per plane
+    static constexpr int PWS = (2 * PI + WAVES - 1) / WAVES;    // slab DMA instructions per wave and pair-step
+    static constexpr int PWW = (2 * WI + WAVES - 1) / WAVES;    // weight DMA instructions per wave and pair-step
+    static constexpr int ND = PWS + PWW;
+    static constexpr int WBYTES = 2 * WI * 1024;                // one weight slot (two planes)
+    static constexpr int WOFF = RS * PLANE;
+    static constexpr int BIAS_OFF = WOFF + 2 * WBYTES;
+    static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
+    static constexpr int T = 3 * (NP + 2);
+    static constexpr int AHEAD = RS / 2 - 1;                    // pair-steps the slab DMA runs ahead
+    static constexpr int NW = (AHEAD - 1) * PWS;                // DMA instructions that may stay in flight at a barrier
+    static_assert(RS % 2 == 0 && RS >= 4, "slab ring holds whole pairs");
+    static_assert((2 * PI) % WAVES == 0, "slab pieces split evenly over the waves");
+    static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
+    static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
+};
+
+template <int CT, int NP, int RS, int EPI>
+__global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
+    using G = TG8<CT, NP, RS>;
+    constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
+    static_assert((EPI == EPI_LRELU && CT == 1) || (kTrunk && CT == 2), "conv1-4: 32 couts; conv5: 64 couts");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pcol = lane & 31, hh = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int slot_in_round = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+    const int tpi = p.tilesX * p.tilesY;
+    const int ntiles = tpi * p.N;
+    const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;
+    if (my_tiles <= 0) return;
+    const int NSTEP = p.nstage >> 1;                             // pair-steps per patch (nstage is even, host)
+    const int nreal = p.seg_len;                                 // real planes; the rest are phantoms
+    const uint32_t sblk = (uint32_t)p.sHp * p.sWp * 32;          // bytes between planes
+    const size_t oblk = (size_t)p.Hp * p.Wp * 32;
+
+    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
+    int sa[CT];                                                  // E8M0 weight scale of my cout row, per cout tile
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) sa[ct] = p.wscale[ct * 32 + pcol];
+
+    // ---- per-lane global offsets of my DMA pieces.  Slab piece i = wave + 4*sl of the pair: plane i / PI, piece i % PI.
+    uint32_t loffS[G::PWS];
+#pragma unroll
+    for (int sl = 0; sl < G::PWS; ++sl) {
+        const int jj = (wave + sl * 4) % G::PI;
+        const int i = jj * 64 + lane;
+        int q = i >> 1;
+        if (q >= G::SPX) q = 0;
+        const int ry = q / G::SW, rx = q - ry * G::SW;
+        const int h2 = (i & 1) ^ ((rx >> 3) & 1);
+        loffS[sl] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
+    }
+    const uint32_t lane16 = (uint32_t)lane * 16;
+
+    // ---- two DMA cursors over my pair-steps: slabs (AHEAD steps ahead) and weights (one step ahead); both stay on the
+    // last pair-step of the last patch once they get there
+    struct Cur { int it, st; const char* pbase; };
+    Cur cs{0, 0, nullptr}, cw{0, 0, nullptr};
+    const char* sA = nullptr;   // slab sources of the pair under the slab cursor
+    const char* sB = nullptr;
+    const char* wS = nullptr;   // weights of the pair under the weight cursor
+    auto advance = [&](Cur& c) __attribute__((always_inline)) {
+        if (++c.st == NSTEP) {
+            if (c.it + 1 < my_tiles) { c.st = 0; ++c.it; }
+            else c.st = NSTEP - 1;
+        }
+    };
+    auto slab_next = [&]() __attribute__((always_inline)) {
+        if (cs.st == 0) {
+            const int tile = cs.it * nwg + slot_in_round;
+            const int n = tile / tpi;
+            const int trem = tile - n * tpi;
+            const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+            cs.pbase = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
+        }
+        const int pa = 2 * cs.st, pb = 2 * cs.st + 1;
+        sA = cs.pbase + (size_t)(pa < nreal ? pa : 0) * sblk;
+        sB = cs.pbase + (size_t)(pb < nreal ? pb : 0) * sblk;
+        advance(cs);
+    };
+    auto wts_next = [&]() __attribute__((always_inline)) {
+        wS = (const char*)p.wpack + (size_t)cw.st * G::WBYTES;
+        advance(cw);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    // slab piece sl of the pair whose first plane sits in ring slot `slot0` (the second in slot0 + 1, wrapping)
+    auto dma_slab = [&](int sl, uint32_t slot0) __attribute__((always_inline)) {
+        const int i = wave + sl * 4;
+        const bool second = i >= G::PI;
+        const int jj = second ? i - G::PI : i;
+        uint32_t slot = slot0 + (second ? 1u : 0u);
+        if (slot == (uint32_t)RS) slot = 0;
+        glds16<false>(second ? sB : sA, loffS[sl], lds0 + slot * G::PLANE + (uint32_t)jj * 1024);
+    };
+    auto dma_wts = [&](int sl, uint32_t wslot) __attribute__((always_inline)) {
+        int i = wave + sl * 4;
+        if (i > 2 * G::WI - 1) i = 2 * G::WI - 1;                // padding slot: the last piece again
+        glds16<false>(wS, lane16 + (uint32_t)i * 1024, lds0 + G::WOFF + wslot * G::WBYTES + (uint32_t)i * 1024);
+    };
+
+    // ---- fragment addresses: per-lane base + immediate.  b0 / b1 = logical 16-B halves 0 / 1 of pixel (row, pcol + dx)
+    uint32_t b0base[3], b1base[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int c = pcol + dx, sw = (c >> 3) & 1;
+        b0base[dx] = (uint32_t)((wave * NP) * G::ROWB + c * 32 + 16 * sw);
+        b1base[dx] = (uint32_t)((wave * NP) * G::ROWB + c * 32 + 16 * (1 - sw));
+    }
+    const uint32_t abase = (uint32_t)(G::WOFF + hh * (G::WI * 1024) + pcol * 16);   // my plane's weight block inside a weight slot
+
+    char* const trash = p.trash + (size_t)tid * 16;
+
+    f32x16 acc[CT][NP];
+    v8i acol[3][3][CT];
+    v8i breg[6];
+    auto ldA = [&](uint32_t woff, int tap, int ct) __attribute__((always_inline)) -> v8i {
+        const char* fp = smem + woff + abase + (tap * CT + ct) * 1024;
+        const v4i x0 = *(const v4i*)fp, x1 = *(const v4i*)(fp + 512);
+        return __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto ldB = [&](uint32_t lane_slab, int dx, int s) __attribute__((always_inline)) -> v8i {
+        const v4i x0 = *(const v4i*)(smem + lane_slab + b0base[dx] + s * G::ROWB);
+        const v4i x1 = *(const v4i*)(smem + lane_slab + b1base[dx] + s * G::ROWB);
+        return __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    // ---- prologue
+    uint32_t cur_slot = 0;        // slab ring slot of the current pair's first plane
+    uint32_t cur_w = 0;           // weight slot of the current pair
+    {
+        slab_next();              // slabs of pair-step 0
+#pragma unroll
+        for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl, 0);
+        wts_next();               // weights of pair-step 0
+#pragma unroll
+        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl, 0);
+#pragma unroll
+        for (int a = 1; a < G::AHEAD; ++a) {
+            slab_next();
+#pragma unroll
+            for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl, (uint32_t)(2 * a));
+        }
+    }
+    wait_release_barrier<G::NW>();
+    auto lane_slab_of = [&](uint32_t slot0) __attribute__((always_inline)) -> uint32_t {
+        uint32_t s1 = slot0 + 1;
+        if (s1 == (uint32_t)RS) s1 = 0;
+        return (hh ? s1 : slot0) * (uint32_t)G::PLANE;
+    };
+    {
+        const uint32_t ls = lane_slab_of(0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = ldA(0, dy * 3, ct);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) breg[v] = ldB(ls, 0, v);
+    }
+
+    // One pair-step.  FIRST: first of a patch.  `sb` = E8M0 activation scale of this pair (x planes / growth planes).
+    auto step = [&](auto first_tag, bool first_patch, int sb) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        uint32_t next_slot = cur_slot + 2;
+        if (next_slot >= (uint32_t)RS) next_slot -= RS;
+        // DMA targets: the slabs AHEAD pair-steps ahead go where the previous pair-step's planes were
+        uint32_t dma_slot = cur_slot + 2 * G::AHEAD;
+        while (dma_slot >= (uint32_t)RS) dma_slot -= RS;
+        const uint32_t ls = lane_slab_of(cur_slot), lsn = lane_slab_of(next_slot);
+        const uint32_t wo = cur_w * G::WBYTES, won = (cur_w ^ 1) * G::WBYTES;
+        wts_next();
+        slab_next();
+#pragma unroll
+        for (int t = 0; t < G::T; ++t) {
+            const int dx = t / (NP + 2), s = t % (NP + 2);
+            if (t == G::T - 3) {
+                constexpr int NST = kTrunk ? CT * 4 * NP : CT * NP;      // epilogue stores per wave
+                constexpr int NEPI = (G::NW + NST < 63) ? G::NW + NST : 63;
+                if (FIRST && !first_patch) wait_release_barrier<NEPI>();
+                else wait_release_barrier<G::NW>();
+            }
+            {
+                const int u = t + 3;
+                if (u < G::T) breg[u % 6] = ldB(ls, u / (NP + 2), u % (NP + 2));
+                else breg[u % 6] = ldB(lsn, 0, u - G::T);
+            }
+            if (dx < 2 && s < 3 * CT) {
+                const int dy = s / CT, ct = s % CT;
+                acol[dx + 1][dy][ct] = ldA(wo, dy * 3 + dx + 1, ct);
+            }
+            if (t >= G::T - 3) {
+                const int dy = t - (G::T - 3);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = ldA(won, dy * 3, ct);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA: the next pair-step's weights first, then the slabs AHEAD pair-steps ahead; all in front of the barrier step
+#pragma unroll
+            for (int i = 0; i < G::ND; ++i)
+                if ((i * (G::T - 3)) / G::ND == t) {
+                    if (i < G::PWW) dma_wts(i, cur_w ^ 1);
+                    else dma_slab(i - G::PWW, dma_slot);
+                }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int np = s - dy;
+                if (np < 0 || np >= NP) continue;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (FIRST && dx == 0 && dy == 0) mfma8_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
+                    else mfma8_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur_slot = next_slot;
+        cur_w ^= 1;
+    };
+
+    // e4m3 x4 of four floats scaled by 2^e, clamped to the finite range (v_cvt_pk_fp8_f32 turns overflow into NaN)
+    auto to_e4m3x4 = [&](const f32x4& v, float scale) __attribute__((always_inline)) -> uint32_t {
+        float c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_fmed3f(__fmul_rn(v[i], scale), -448.0f, 448.0f);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+        return (uint32_t)w;
+    };
+    const float oscale = __builtin_ldexpf(1.0f, kTrunk ? p.x_exp : p.g_exp);   // scale of the planes this conv writes
+
+    auto epilogue = [&](int it) __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // MFMA results -> VALU reads (see conv_trunk_f16)
+        const int tile = it * nwg + slot_in_round;
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+        const int y0 = ty * G::TH, x0 = tx * G::TW;
+        const int x = x0 + pcol;
+        f32x16 bv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *(const f32x4*)(smem + G::BIAS_OFF + (ct * 32 + 8 * g + 4 * hh) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = v[i];
+            }
+        bool ok[NP];
+        size_t opix[NP];
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const int y = y0 + wave * NP + np;
+            ok[np] = (y < p.H) && (x < p.W);
+            opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
+        }
+        const size_t xn = (size_t)n * p.xh_img;
+        u32x2 t_in[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
+        u32x2 r_in[EPI == EPI_RDB5_RRDB ? CT : 1][4];
+        if (kTrunk) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
+                            asm_load8(p.xh_in + xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
+            if (EPI == EPI_RDB5) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) asm_land(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            if (EPI == EPI_RDB5_RRDB) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g] =
+                            asm_load8(p.xh_skip + xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        asm_land(r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                        if (np == 0) {
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) asm_land(t_in[kTrunk ? ct : 0][kTrunk ? q : 0][g]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                u32x2 hpk[4];
+                uint32_t q8[4];     // e4m3 x4 per g: channels 8g+4hh.. of plane ct -> dword 2g+hh of the pixel's 32 bytes
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
+                    if (EPI == EPI_LRELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                    } else {
+                        const f32x4 th = half4_to_float(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), th[i]);
+                            if (EPI == EPI_RDB5_RRDB) {
+                                const f32x4 rr = half4_to_float(r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                                v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), rr[i]);
+                            }
+                        }
+                        f16x4 hv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
+                        hpk[g] = __builtin_bit_cast(u32x2, hv);
+                        // the conv operand is the e4m3 image of what the trunk actually carries (the fp16 value)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (float)hv[i];
+                    }
+                    q8[g] = to_e4m3x4(v, oscale);
+                }
+                // e4m3 plane: after the swaps lanes 0-31 hold dwords 0-3 of the pixel, lanes 32-63 dwords 4-7
+                {
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(q8[0], q8[2], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(q8[1], q8[3], false, false);
+                    u32x4 o;
+                    o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
+                    *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)ct * oblk + opix[np] * 32 + hh * 16 : trash) = o;
+                }
+                if (kTrunk) {
+#pragma unroll
+                    for (int bk = 0; bk < 2; ++bk) {
+                        u32x2 lo = hpk[2 * bk], hi = hpk[2 * bk + 1];
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(lo[0], hi[0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
+                        u32x4 o;
+                        o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
+                        *(u32x4*)(ok[np] ? p.xh_out + xn + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
+                    }
+                }
+            }
+        }
+    };
+
+    using std::integral_constant;
+    const int sbx = 127 - p.x_exp, sbg = 127 - p.g_exp;
+    for (int it = 0; it < my_tiles; ++it) {
+        step(integral_constant<bool, true>{}, it == 0, sbx);      // planes 0, 1 = x
+        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, false, sbg);
+        epilogue(it);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CT, int NP, int RS, int EPI>
+hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
+    using G = TG8<CT, NP, RS>;
+    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS rings do not fit");
+    static_assert(G::NW >= 0 && G::NW < 64, "vmcnt field is 6 bits");
+    auto kern = conv_trunk_f8<CT, NP, RS, EPI>;
+    static std::mutex attr_mu;
+    static bool attr_set[64] = {false};
+    static int ncu_dev[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int ncu;
+    {
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (!attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            int n = 256;
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            ncu_dev[dev] = n;
+            attr_set[dev] = true;
+        }
+        ncu = ncu_dev[dev];
+    }
+    // operand shapes the kernel's indexing assumes
+    if (p.nstage < 2 || p.nstage > 6 || (p.nstage & 1) || p.seg_len < 1 || p.seg_len > p.nstage) return hipErrorInvalidValue;
+    if (p.sHp != p.Hp || p.sWp != p.Wp) return hipErrorInvalidValue;
+    if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;
+    if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash || !p.wscale) return hipErrorInvalidValue;
+    if (p.x_exp < -8 || p.x_exp > 16 || p.g_exp < -8 || p.g_exp > 16) return hipErrorInvalidValue;
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (!p.xh_in || !p.xh_out || (EPI == EPI_RDB5_RRDB && !p.xh_skip))) return hipErrorInvalidValue;
+    ConvParams q = p;
+    q.tilesX = (p.W + G::TW - 1) / G::TW;
+    q.tilesY = (p.H + G::TH - 1) / G::TH;
+    const int ntiles = q.tilesX * q.tilesY * p.N;
+    int grid = ncu & ~7;
+    if (ntiles < grid) grid = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, q);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // ct = 1: conv1..4 (EPI_LRELU); ct = 2: conv5 (EPI_RDB5 / EPI_RDB5_RRDB).  Returns hipErrorNotSupported for
@@ -522,4 +968,54 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
     return hipErrorNotSupported;
 }
 
+}  // namespace s2sr
+
+namespace s2sr {
+
+size_t conv_wpack_bytes_f8(int cin, int cout) {
+    const int nreal = (cin + 31) / 32, npad = (nreal + 1) & ~1, CT = (cout + 31) / 32;
+    return (size_t)npad * 9 * CT * 1024;
+}
+
+// w: OIHW fp32.  Per output channel a power-of-two scale 2^k_co puts max|w_co| into [224, 448) -- the top binade of
+// e4m3, so every weight keeps its 3 mantissa bits unless it is more than 2^8 below its row's maximum -- and the MFMA
+// takes 2^-k_co back out through scale_a.  wscale_out[co] = the E8M0 byte 127 - k_co.
+void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int32_t* wscale_out) {
+    const int nreal = (cin + 31) / 32, npad = (nreal + 1) & ~1, CT = (cout + 31) / 32;
+    int kco[64];
+    for (int co = 0; co < 64; ++co) {
+        float m = 0.f;
+        if (co < cout)
+            for (size_t i = 0; i < (size_t)cin * 9; ++i) m = fmaxf(m, fabsf(w[(size_t)co * cin * 9 + i]));
+        int k = 0;
+        if (m > 0.f) {
+            k = (int)floorf(log2f(448.0f / m));
+            while (ldexpf(m, k) >= 448.0f) --k;          // guard the rounding of log2f at the binade edge
+            while (ldexpf(m, k + 1) < 448.0f) ++k;
+        }
+        if (k > 100) k = 100;
+        if (k < -100) k = -100;
+        kco[co] = k;
+        wscale_out[co] = 127 - k;
+    }
+    uint8_t* d = (uint8_t*)dst_host;
+    for (int pl = 0; pl < npad; ++pl)
+        for (int t = 0; t < 9; ++t)
+            for (int ct = 0; ct < CT; ++ct)
+                for (int h16 = 0; h16 < 2; ++h16)
+                    for (int row = 0; row < 32; ++row)
+                        for (int j = 0; j < 16; ++j) {
+                            const int co = ct * 32 + row, ci = 32 * pl + 16 * h16 + j;
+                            float v = 0.f;
+                            if (pl < nreal && co < cout && ci < cin) v = ldexpf(w[((size_t)co * cin + ci) * 9 + t], kco[co]);
+                            *d++ = f32_to_e4m3(v);
+                        }
+}
+
+hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_t st) {
+    if (ct == 1 && epi == EPI_LRELU) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
+    if (ct == 2 && epi == EPI_RDB5) return launch_trunk8_t<2, 4, 4, EPI_RDB5>(p, st);
+    if (ct == 2 && epi == EPI_RDB5_RRDB) return launch_trunk8_t<2, 4, 4, EPI_RDB5_RRDB>(p, st);
+    return hipErrorNotSupported;
+}
 }  // namespace s2sr

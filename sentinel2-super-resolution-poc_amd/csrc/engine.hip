@@ -27,6 +27,10 @@ struct ConvW {
     void* d_wphase[2] = {nullptr, nullptr};   // hp up-convs: the 2x2 sub-pixel kernels per output row parity (pack_conv_weights_phase_f8hp)
     void* d_wpack = nullptr;
     float* d_bias = nullptr;
+    // fp8 trunk mode (S2SR_PREC_FP8), the 345 RDB convs: e4m3 weight planes (pack_conv_weights_f8; nstage = planes padded
+    // to even, seg_len = real planes) + per-output-channel E8M0 scale bytes
+    bool f8trunk = false;
+    int32_t* d_wscale = nullptr;
 };
 
 // kernel families for the HIP-event statistics
@@ -49,7 +53,13 @@ struct Workspace {
     // split-operand mode only: e4m3 correction planes of U0..U3 and of the trunk, 4 planes of 32 B per
     // pixel each ([lo*2^11 p0, p1, hi p0, p1]) -- the size of a 4-block fp16 tensor
     char *U0lo = nullptr, *U1lo = nullptr, *U2lo = nullptr, *U3lo = nullptr, *T8 = nullptr;
-    bool hp = false;
+    // fp8 trunk mode only: the dense-block tensors as e4m3 planes of 32 channels [x(2) | x1 | x2 | x3 | x4], the trunk x in
+    // fp16 (three rotating buffers: an RRDB's input stays readable until its last conv5 has used it as the skip), and
+    // an all-zero "trunk lo" for conv_body's split-operand path
+    char *D8[2] = {nullptr, nullptr};
+    char *Xh[3] = {nullptr, nullptr, nullptr};
+    char *Tz = nullptr;
+    bool hp = false, fp8 = false;
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
     size_t blk1 = 0, blk2 = 0, blk4 = 0;   // bytes of one block plane at 1x / 2x / 4x
 };
@@ -97,6 +107,7 @@ struct s2sr_handle {
     hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
     std::vector<hipEvent_t> group_done;
     // hipGraph replay of repeated groups
+    int fp8_x_exp = 4, fp8_g_exp = 6;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     std::vector<GraphEntry> graphs;
@@ -164,15 +175,16 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     Workspace& w = h->ws;
-    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP;
-    if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp) return S2SR_OK;
+    const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || fp8;   // split-operand head / tail convs
+    if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp && w.fp8 == fp8) return S2SR_OK;
     if (w.base) {
         HIPCHK(h, hipDeviceSynchronize());
         drop_graphs(h);
         HIPCHK(h, hipFree(w.base));
         w = Workspace();
     }
-    w.G = G; w.H = H; w.W = W; w.hp = hp;
+    w.G = G; w.H = H; w.W = W; w.hp = hp; w.fp8 = fp8;
     w.Hp = padded(H); w.Wp = padded(W);
     w.Hp2 = padded(2 * H); w.Wp2 = padded(2 * W);
     w.Hp4 = padded(4 * H); w.Wp4 = padded(4 * W);
@@ -180,7 +192,8 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
     const size_t g = (size_t)G;
-    const size_t oP0 = take(g * w.blk1), oD0 = take(g * 12 * w.blk1), oD1 = take(g * 12 * w.blk1),
+    const size_t nd = fp8 ? 0 : 12;     // the fp16 dense tensors are not used by the fp8 trunk
+    const size_t oP0 = take(g * w.blk1), oD0 = take(g * nd * w.blk1), oD1 = take(g * nd * w.blk1),
                  oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oR = take(g * 8 * w.blk1),
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
@@ -190,6 +203,12 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
         oU0l = take(g * 4 * w.blk1); oU1l = take(g * 4 * w.blk2); oU2l = take(g * 4 * w.blk4); oU3l = take(g * 4 * w.blk4);
         oT8 = take(g * 4 * w.blk1);
     }
+    size_t oD8[2] = {0, 0}, oXh[3] = {0, 0, 0}, oTz = 0;
+    if (fp8) {
+        for (int i = 0; i < 2; ++i) oD8[i] = take(g * 6 * w.blk1);
+        for (int i = 0; i < 3; ++i) oXh[i] = take(g * 4 * w.blk1);
+        oTz = take(g * 4 * w.blk1);
+    }
     w.bytes = off;
     HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
@@ -198,6 +217,11 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     w.T = w.base + oT; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
     if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; w.T8 = w.base + oT8; }
+    if (fp8) {
+        for (int i = 0; i < 2; ++i) w.D8[i] = w.base + oD8[i];
+        for (int i = 0; i < 3; ++i) w.Xh[i] = w.base + oXh[i];
+        w.Tz = w.base + oTz;
+    }
     return S2SR_OK;
 }
 
@@ -306,33 +330,77 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
     b.N = n; b.H = H; b.W = W; b.Hp = w.Hp; b.Wp = w.Wp; b.sHp = w.Hp; b.sWp = w.Wp;
     b.T = w.T; b.R = w.R; b.F = w.F;
     int ci = 0, rc;
+    const bool fp8 = w.fp8;
     {   // conv_first: 3 -> 64 (input = one 16-channel block)
         ConvParams p = b;
-        p.src = w.P0; p.src_img = w.blk1; p.dst = w.D[0]; p.dst_img = 12 * w.blk1; p.in_scale = 1.0f / 255.0f;
+        p.src = w.P0; p.src_img = w.blk1; p.in_scale = 1.0f / 255.0f;
+        if (fp8) { p.dst = w.Xh[0]; p.dst_img = 4 * w.blk1; }
+        else { p.dst = w.D[0]; p.dst_img = 12 * w.blk1; }
         if ((rc = run_conv(h, st, F_FIRST, h->convs[ci++], p, EPI_FIRST, false))) return rc;
     }
     int cur = 0;
-    for (int blk = 0; blk < nb; ++blk)
-        for (int r = 0; r < 3; ++r) {
-            for (int k = 1; k <= 4; ++k) {
+    const char* trunk_hi = nullptr;   // fp16 x of the trunk after the body (conv_body's main operand)
+    uint64_t trunk_hi_img = 0;
+    const char* trunk_lo = nullptr;   // its fp16 lo half
+    if (fp8) {
+        // the trunk on e4m3 operands (conv_trunk.hip, conv_trunk_f8): D8[cur] planes [x(2) | x1 | x2 | x3 | x4]
+        const int xe = h->fp8_x_exp, ge = h->fp8_g_exp;
+        const double px = (double)n * H * W;
+        {
+            Scope sc(h, st, F_MISC, 0.0, (double)n * w.Hp * w.Wp * (128.0 + 64.0));
+            HIPCHK(h, launch_xh_to_fp8(w.Xh[0], 4 * w.blk1, n, w.Hp, w.Wp, xe, w.D8[0], 6 * w.blk1, st));
+        }
+        for (int blk = 0; blk < nb; ++blk)
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 1; k <= 5; ++k) {
+                    const ConvW& cw = h->convs[ci++];
+                    ConvParams p = b;
+                    p.src = w.D8[cur]; p.src_img = 6 * w.blk1;
+                    p.wpack = cw.d_wpack; p.bias = cw.d_bias; p.wscale = cw.d_wscale;
+                    p.nstage = cw.nstage; p.seg_len = cw.seg_len; p.trash = h->d_trash;
+                    p.x_exp = xe; p.g_exp = ge; p.xh_img = 4 * w.blk1;
+                    int epi = EPI_LRELU;
+                    double bytes = px * (32.0 * cw.seg_len);                     // algorithmic: every input byte once
+                    if (k < 5) {
+                        p.dst = w.D8[cur] + (size_t)(2 + (k - 1)) * w.blk1; p.dst_img = 6 * w.blk1;
+                        bytes += px * 32.0;
+                    } else {
+                        p.dst = w.D8[cur ^ 1]; p.dst_img = 6 * w.blk1;
+                        p.xh_in = w.Xh[r]; p.xh_out = w.Xh[(r + 1) % 3];
+                        epi = EPI_RDB5;
+                        bytes += px * (64.0 + 128.0 + 128.0);                     // e4m3 x out, fp16 trunk in + out
+                        if (r == 2) { p.xh_skip = w.Xh[0]; epi = EPI_RDB5_RRDB; bytes += px * 128.0; }
+                    }
+                    Scope sc(h, st, k < 5 ? F_RDB14 : F_RDB5, 2.0 * 9.0 * cw.cin * cw.cout * px, bytes);
+                    HIPCHK(h, launch_conv_trunk_f8(p, cw.ct, epi, st));
+                }
+                cur ^= 1;
+            }
+        trunk_hi = w.Xh[0]; trunk_hi_img = 4 * w.blk1; trunk_lo = w.Tz;
+    } else {
+        for (int blk = 0; blk < nb; ++blk)
+            for (int r = 0; r < 3; ++r) {
+                for (int k = 1; k <= 4; ++k) {
+                    ConvParams p = b;
+                    p.src = w.D[cur]; p.src_img = 12 * w.blk1;
+                    p.dst = w.D[cur] + (size_t)(4 + 2 * (k - 1)) * w.blk1; p.dst_img = 12 * w.blk1;
+                    if ((rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false))) return rc;
+                }
                 ConvParams p = b;
                 p.src = w.D[cur]; p.src_img = 12 * w.blk1;
-                p.dst = w.D[cur] + (size_t)(4 + 2 * (k - 1)) * w.blk1; p.dst_img = 12 * w.blk1;
-                if ((rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false))) return rc;
+                p.dst = w.D[cur ^ 1]; p.dst_img = 12 * w.blk1;
+                if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
+                cur ^= 1;
             }
-            ConvParams p = b;
-            p.src = w.D[cur]; p.src_img = 12 * w.blk1;
-            p.dst = w.D[cur ^ 1]; p.dst_img = 12 * w.blk1;
-            if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
-            cur ^= 1;
-        }
+        trunk_hi = w.D[cur]; trunk_hi_img = 12 * w.blk1; trunk_lo = w.T;
+    }
     const bool hp = w.hp;   // split-operand head/tail: inputs as (hi, lo) pairs, outputs write both halves
-    {   // conv_body + global skip; its input is the trunk: hi = x (dense blocks 0..3), lo = trunk lo
+    {   // conv_body + global skip; its input is the trunk: hi = x, lo = trunk lo (all zero in fp8 mode: the trunk is fp16 there)
         ConvParams p = b;
-        p.src = w.D[cur]; p.src_img = 12 * w.blk1; p.dst = w.U0; p.dst_img = 4 * w.blk1;
+        p.src = trunk_hi; p.src_img = trunk_hi_img; p.dst = w.U0; p.dst_img = 4 * w.blk1;
         if (hp) {
             Scope sc(h, st, F_MISC, 0.0, (double)n * w.Hp * w.Wp * (256.0 + 128.0));
-            HIPCHK(h, launch_trunk_to_fp8(w.D[cur], 12 * w.blk1, w.T, 4 * w.blk1, n, w.Hp, w.Wp, w.T8, st));
+            HIPCHK(h, launch_trunk_to_fp8(trunk_hi, trunk_hi_img, trunk_lo, 4 * w.blk1, n, w.Hp, w.Wp, w.T8, st));
             p.src_lo = w.T8; p.lo_img = 4 * w.blk1; p.T = w.U0lo;
         }
         if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false, hp))) return rc;
@@ -487,7 +555,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     *out = nullptr;
     if (cfg->num_block <= 0 || cfg->num_feat != 64 || cfg->num_grow != 32 || cfg->scale != 4)
         return fail(nullptr, S2SR_E_INVALID, "unsupported net shape (need num_feat=64, num_grow=32, scale=4)");
-    if (cfg->precision != S2SR_PREC_F16 && cfg->precision != S2SR_PREC_F16_HP)
+    if (cfg->precision != S2SR_PREC_F16 && cfg->precision != S2SR_PREC_F16_HP && cfg->precision != S2SR_PREC_FP8)
         return fail(nullptr, S2SR_E_INVALID, "unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -511,6 +579,8 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     }
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
+    if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
@@ -533,6 +603,7 @@ void s2sr_destroy(s2sr_handle* h) {
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
+        if (c.d_wscale) hipFree(c.d_wscale);
         for (int k = 0; k < 2; ++k)
             if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
     }
@@ -564,6 +635,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     for (ConvW& c : h->convs) {
         if (c.d_wpack) hipFree(c.d_wpack);
         if (c.d_bias) hipFree(c.d_bias);
+        if (c.d_wscale) hipFree(c.d_wscale);
         for (int k = 0; k < 2; ++k)
             if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
     }
@@ -571,7 +643,8 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     h->has_weights = false;
     const float* pw = blob;
     std::vector<char> tmp;
-    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP;
+    const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || fp8;
     const size_t nconv = specs.size();
     size_t idx = 0;
     for (const ConvSpec& s : specs) {
@@ -589,9 +662,19 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
         cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold || f8) ? 0x2 : 0x0;
         cw.f8 = f8;
-        const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
+        const bool f8trunk = fp8 && !split;             // the 345 RDB convs
+        const size_t wb = f8trunk ? conv_wpack_bytes_f8(s.cin, s.cout) : conv_wpack_bytes_seg(s.cin, s.cout, nseg);
         tmp.resize(wb);
-        if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
+        if (f8trunk) {
+            int32_t wsc[64];
+            pack_conv_weights_f8(pw, s.cin, s.cout, tmp.data(), wsc);
+            cw.f8trunk = true;
+            cw.seg_len = (s.cin + 31) / 32;
+            cw.nstage = (cw.seg_len + 1) & ~1;
+            cw.seg_lo_mask = 0;
+            HIPCHK(h, hipMalloc((void**)&cw.d_wscale, sizeof wsc));
+            HIPCHK(h, hipMemcpy(cw.d_wscale, wsc, sizeof wsc, hipMemcpyHostToDevice));
+        } else if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
         else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
         cw.fold = fold;
         if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2

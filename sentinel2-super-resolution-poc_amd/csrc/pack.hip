@@ -103,6 +103,43 @@ hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, si
     return hipGetLastError();
 }
 
+// fp8 trunk mode: the trunk x (fp16, 4 blocks of 16 channels) -> the two e4m3 planes e4m3(x * 2^x_exp) the RDB convs
+// read (whole padded tensor: halo zeros stay zeros).  One thread = one pixel of one plane.
+__global__ void xh_to_fp8_kernel(const char* __restrict__ xh, size_t xh_img, int N, size_t ppx, float scale, char* __restrict__ out,
+                                 size_t out_img) {
+    const size_t total = (size_t)N * 2 * ppx;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i % ppx;
+        const int plane = (int)((i / ppx) & 1);
+        const int n = (int)(i / (2 * ppx));
+        const char* src = xh + (size_t)n * xh_img + (size_t)(2 * plane) * ppx * 32 + pix * 32;
+        uint32_t o[8];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const f16* v = (const f16*)(src + (size_t)b * ppx * 32);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = __builtin_amdgcn_fmed3f((float)v[4 * q + k] * scale, -448.0f, 448.0f);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+                o[4 * b + q] = (uint32_t)w;
+            }
+        }
+        uint4* d = (uint4*)(out + (size_t)n * out_img + (size_t)plane * ppx * 32 + pix * 32);
+        d[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        d[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+hipError_t launch_xh_to_fp8(const char* xh, size_t xh_img, int N, int Hp, int Wp, int x_exp, char* out, size_t out_img, hipStream_t st) {
+    const size_t ppx = (size_t)Hp * Wp, total = (size_t)N * 2 * ppx;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(xh_to_fp8_kernel, dim3(grid), dim3(256), 0, st, xh, xh_img, N, ppx, ldexpf(1.0f, x_exp), out, out_img);
+    return hipGetLastError();
+}
+
 __global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
                                       int T, int wh, int ww, uint8_t* __restrict__ tiles) {
     const size_t total = (size_t)T * wh * ww * 3;

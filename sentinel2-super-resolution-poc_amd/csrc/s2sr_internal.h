@@ -71,6 +71,15 @@ struct ConvParams {
     int32_t act;             // EPI_DEBUG: apply lrelu
     int32_t fold_lo;         // EPI_LAST: couts 8..8+cout-1 carry w_lo (pack_conv_weights fold): out[c] = acc[c] + acc[8+c]
     float in_scale;          // EPI_FIRST: 1/255 (inputs are fed as exact integers 0..255)
+    // fp8 trunk mode (S2SR_PREC_FP8, conv_trunk.hip conv_trunk_f8): src / dst are e4m3 PLANES of 32 channels (32 B per
+    // pixel, the geometry of an fp16 block-16 plane); nstage = planes per patch padded to an even count, seg_len = real
+    // planes (a phantom plane re-reads plane 0 against zero weights); the trunk itself is carried in fp16:
+    const char* xh_in;       // conv5: trunk x (fp16 blocked-16, 4 blocks) -- the residual operand
+    const char* xh_skip;     // conv5 of rdb3: the RRDB's input x (fp16, 4 blocks)
+    char* xh_out;            // conv5: new trunk x (fp16, 4 blocks); may alias xh_skip (same lane reads, then writes)
+    uint64_t xh_img;         // bytes between images of the three
+    const int32_t* wscale;   // [64] E8M0 bytes 127 - k_co of the per-output-channel weight scales 2^k_co
+    int32_t x_exp, g_exp;    // activation scales: x planes hold e4m3(x * 2^x_exp), growth planes e4m3(x_k * 2^g_exp)
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
     int32_t dbg;                 // diagnostic only (timing ablations, results wrong): 1 weights DMA from one fixed piece,
@@ -83,6 +92,13 @@ hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // 
 // the RRDB trunk convs as one-wave-per-SIMD workgroups (conv_trunk.hip): ct 1 + EPI_LRELU (conv1..4), ct 2 + EPI_RDB5 /
 // EPI_RDB5_RRDB (conv5).  hipErrorNotSupported = not a trunk form / launch too small: use launch_conv.
 hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace = false);
+// the same convs on e4m3 operands, block-scaled fp8 MFMA (K = 64 = two planes per instruction)
+hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_t st);
+// per-plane weight stages for conv_trunk_f8: [plane][tap][ct][16-B half][cout row 0..31][16 channel bytes] e4m3 of
+// w * 2^k_co, planes padded to an even count with a zero plane; wscale_out[co] = 127 - k_co
+size_t conv_wpack_bytes_f8(int cin, int cout);
+void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int32_t* wscale_out /*[64]*/);
+hipError_t launch_xh_to_fp8(const char* xh, size_t xh_img, int N, int Hp, int Wp, int x_exp, char* out, size_t out_img, hipStream_t st);
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]
 // nseg 1: [w_hi]; 2: [w_hi][w_lo] (exact-integer inputs: conv_first); 3: [w_hi][w_hi][w_lo]

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("S2SR_LIB", _HERE.parent / "csrc" / "libs2sr.so"))
 
-PREC_F16, PREC_F16_HP = 0, 1
+PREC_F16, PREC_F16_HP, PREC_FP8 = 0, 1, 2
 _ERR = {-1: "invalid argument", -2: "HIP error", -3: "weights not loaded", -4: "bad weight blob",
         -5: "no gfx950 device (no CPU fallback exists)", -6: "buffer too small"}
 

@@ -204,3 +204,23 @@ def test_http_enhance_upload_runs_on_gpu(monkeypatch, tmp_path):
     exp = pp.enhance_for_crops(np.ascontiguousarray(exp[:, :, ::-1]))
     d = np.abs(out.astype(np.int16) - exp.astype(np.int16))
     assert out.shape == (80, 112, 3) and np.mean(d == 0) > 0.9
+
+
+def test_farm_sr_on_fp8_trunk(monkeypatch, tmp_path):
+    """BASELINE.json configs[4]: the /api/sr variant (process_farm_sr) selected onto the fp8 trunk by
+    S2SR_FARM_PRECISION=fp8; pixels stay within the mode's measured tolerance of the default-precision job."""
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_x4": 23})
+    from app.farm_sr import process_farm_sr
+    rgb = np.random.default_rng(4).integers(0, 256, (24, 32, 3), dtype=np.uint8)
+    src = tmp_path / "scene.tif"
+    rio.write_geotiff_rgb(src, rgb, rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)}))
+    a = process_farm_sr(src, tmp_path / "hp", scale=4)
+    monkeypatch.setenv("S2SR_FARM_PRECISION", "fp8")
+    b = process_farm_sr(src, tmp_path / "f8", scale=4)
+    ia, _ = rio.read_rgb_u8(a["outputs"]["sr_tif"])
+    ib, _ = rio.read_rgb_u8(b["outputs"]["sr_tif"])
+    d = np.abs(ia.astype(np.int16) - ib.astype(np.int16))
+    print(f"farm_sr fp8 vs hp: max {d.max()} LSB, identical {np.mean(d == 0):.4f}")
+    assert ia.shape == ib.shape == (96, 128, 3) and not np.array_equal(ia, ib) and d.max() <= 40 and np.mean(d <= 2) > 0.9
+    import app.cnn_super_resolution as m
+    assert len({k[2] for k in m._ENGINES}) >= 2          # two engines: default precision and fp8

@@ -525,3 +525,64 @@ def test_rccl_world1_path():
         e.close()
     finally:
         dist.destroy_process_group()
+
+
+# S2SR_PREC_FP8 (BASELINE.json configs[4]): the 345 RDB convs on e4m3 operands.  e4m3 keeps 3 mantissa bits, so this mode
+# is NOT inside the north star's 1e-3; its tolerance is what it measures (MI355X, seeded x4plus-shaped weights):
+#   23 blocks: max-abs 5.5e-3 (rms 8.8e-4) at |y| max 2.7;  unscaled-body stress weights 1.7e-2;  6 blocks 9e-5
+TOL_FP8_23 = 1.5e-2
+TOL_FP8_STRESS = 5e-2
+TOL_FP8_6 = 1e-3
+
+
+def test_fp8_mode_measured_tolerance(golden_dir):
+    F8 = native.PREC_FP8
+    g = np.load(golden_dir / "g4_full_nets.npz")
+    for nb, key, kw, tol in ((23, "y_b23", {}, TOL_FP8_23), (6, "y_b6", {}, TOL_FP8_6),
+                             (23, "y_b23_gain1", {"body_gain": 1.0}, TOL_FP8_STRESS)):
+        y = engine(nb, F8, **kw).forward_f32(g["x"])
+        d = np.abs(y - g[key])
+        print(f"fp8 g4 nb={nb} {kw}: max-abs {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e} (|y| max {np.abs(g[key]).max():.3f})")
+        assert np.isfinite(y).all() and d.max() <= tol
+    g3 = np.load(golden_dir / "g3_small_nets.npz")
+    for nb, key in ((1, "y_b1"), (2, "y_b2")):
+        assert np.abs(engine(nb, F8).forward_f32(g3["x"]) - g3[key]).max() <= TOL_FP8_6
+    g5 = np.load(golden_dir / "g5_enhance_b23.npz")
+    q = engine(23, F8).enhance_u8(g5["img"])
+    d = np.abs(q.astype(np.int16) - g5["out_u8"].astype(np.int16))
+    print(f"fp8 g5 u8: max {d.max()} LSB, identical {np.mean(d == 0):.4f}")
+    assert d.max() <= 3 and np.mean(d == 0) >= 0.85
+    g6 = np.load(golden_dir / "g6_tiled_small.npz")
+    f6 = engine(1, F8).enhance_f32(g6["img"], tile=int(g6["tile_size"]), pad=int(g6["tile_pad"]))
+    assert np.abs(f6 - g6["out_f32"]).max() <= TOL_FP8_6
+
+
+def test_fp8_mode_full_tile_and_batch_properties():
+    """configs[4] at full size: one 256x256 tile through the 23-block net against the oracle (measured tolerance),
+    and the size-independent properties of the batch path (repeat, permutation, rerun, single-vs-batch)."""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    from s2sr.synth import synthetic_tiles
+    F8 = native.PREC_FP8
+    e = engine(23, F8)
+    tiles = synthetic_tiles(20, 256, seed=77)
+    tiles[11] = tiles[2]
+    q_ref, f_ref = ref.enhance(tiles[0], ref.to_torch_sd(synthetic_state_dict(23, seed=0)), 23, return_float=True)
+    f = e.enhance_f32(tiles[0])
+    d = np.abs(f - f_ref)
+    q = e.enhance_u8(tiles[0])
+    dq = np.abs(q.astype(np.int16) - q_ref.astype(np.int16))
+    print(f"fp8 256x256, 23 blocks: float max-abs {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e}; u8 max {dq.max()} LSB, "
+          f"identical {np.mean(dq == 0):.4f}")
+    assert np.isfinite(f).all() and d.max() <= TOL_FP8_23 and dq.max() <= 4 and np.mean(dq == 0) > 0.6
+    y = e.forward_batch_u8(tiles)
+    assert np.array_equal(y[11], y[2]) and np.array_equal(e.forward_batch_u8(tiles), y)
+    perm = np.random.default_rng(1).permutation(len(tiles))
+    assert np.array_equal(e.forward_batch_u8(tiles[perm]), y[perm])
+    assert np.array_equal(e.forward_batch_u8(tiles[5:6])[0], y[5])
+    assert np.array_equal(y[0], q)
+    # ragged sizes (patches hanging over the image edge, one-pixel images) stay finite and close to the HP mode
+    hp = engine(23, native.PREC_F16_HP)
+    for (H, W) in [(1, 1), (17, 45), (70, 33)]:
+        img = np.random.default_rng(H).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        a, b = e.enhance_f32(img), hp.enhance_f32(img)
+        assert a.shape == (4 * H, 4 * W, 3) and np.isfinite(a).all() and np.abs(a - b).max() <= TOL_FP8_23, (H, W)
