@@ -125,7 +125,7 @@ __device__ __forceinline__ void wait_release_barrier() {
 
 template <int EPI, int CT, int NP>
 struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3x3.hip EpiStores)
-    static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : (EPI == EPI_RDB5) ? CT * 4 * NP : CT * 8 * NP;
+    static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : CT * 4 * NP;
 };
 
 template <int CT, int NP, int R, int EPI, bool TRACE>
@@ -337,17 +337,17 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             ok[np] = (y < p.H) && (x < p.W);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
-        const size_t tn = (size_t)n * 8 * oblk;   // image offset inside an fp32 skip tensor (R), bytes
-        const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensor, bytes
+        const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensors, bytes
         u32x2 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
-        f32x4 res1[EPI == EPI_RDB5_RRDB ? CT : 1][4];
+        u32x2 rhi[EPI == EPI_RDB5_RRDB ? CT : 1][4], rlo[EPI == EPI_RDB5_RRDB ? CT : 1][4];   // RRDB skip as an fp16 pair
+        const size_t sn = (size_t)n * p.xh_img;   // image offset inside the skip-hi tensor, bytes
         auto load_lo = [&](int np) __attribute__((always_inline)) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
-                        asm_load8((const char*)p.T + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
+                        asm_load8(p.xh_in + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);   // xh_in: the trunk lo coming in
         };
         if (kTrunk) {
 #pragma unroll
@@ -369,14 +369,18 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        res1[ct][g] = asm_load16((const char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16);
+                    for (int g = 0; g < 4; ++g) {
+                        const size_t off = (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8;
+                        rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g] = asm_load8(p.xh_skip + sn + off);
+                        rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g] = asm_load8(p.lo_skip + ln + off);
+                    }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        asm_land(res1[ct][g]);
+                        asm_land(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                        asm_land(rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
                         if (np == 0) {
 #pragma unroll
                             for (int q = 0; q < NP; ++q) asm_land(lo_old[ct][q][g]);
@@ -399,14 +403,18 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         // t = hi + lo (exact in fp32); hi was captured from LDS: block ct*2 + (g>>1), half g&1
                         const f32x4 th = half4_to_float(hi_cap[kTrunk ? (ct * 2 + (g >> 1)) & 3 : 0][kTrunk ? np : 0][g & 1]);
                         const f32x4 tl = half4_to_float(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+                        f32x4 rs;
+                        if (EPI == EPI_RDB5_RRDB) {
+                            const f32x4 a = half4_to_float(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]), b = half4_to_float(rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rs[i] = __fadd_rn(a[i], b[i]);     // the trunk at the RRDB's input (exact in fp32)
+                        }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const float t = __fadd_rn(th[i], tl[i]);
                             v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), t);
-                            if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), res1[EPI == EPI_RDB5_RRDB ? ct : 0][g][i]);
+                            if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), rs[i]);
                         }
-                        if (EPI == EPI_RDB5_RRDB)
-                            *(f32x4*)(ok[np] ? (char*)p.R + tn + (size_t)(ct * 4 + g) * oblk + opix[np] * 32 + hh * 16 : trash) = v;
                     }
                     f16x4 hv;
 #pragma unroll
@@ -491,7 +499,8 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     }
     // operand shapes the kernel's indexing assumes (a violation would read or write outside the tensors)
     if (p.nstage < 1 || p.nstage > 12 || p.sHp != p.Hp || p.sWp != p.Wp || p.Hp < p.H + 2 || p.Wp < p.W + 2) return hipErrorInvalidValue;
-    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 4 || !p.T || (EPI == EPI_RDB5_RRDB && !p.R))) return hipErrorInvalidValue;
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 4 || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
+        return hipErrorInvalidValue;   // T = trunk lo out, xh_in = trunk lo in, (xh_skip, lo_skip) = the RRDB's input as an fp16 pair
     if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;   // slabs of edge patches stay inside the plane
     if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash) return hipErrorInvalidValue;
     ConvParams q = p;
@@ -704,7 +713,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     }
 
     // One pair-step.  FIRST: first of a patch.  `sb` = E8M0 activation scale of this pair (x planes / growth planes).
-    auto step = [&](auto first_tag, bool first_patch, int sb) __attribute__((always_inline)) {
+    auto step = [&](auto first_tag, int sb) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         uint32_t next_slot = cur_slot + 2;
         if (next_slot >= (uint32_t)RS) next_slot -= RS;
@@ -719,10 +728,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
             if (t == G::T - 3) {
-                constexpr int NST = kTrunk ? CT * 4 * NP : CT * NP;      // epilogue stores per wave
-                constexpr int NEPI = (G::NW + NST < 63) ? G::NW + NST : 63;
-                if (FIRST && !first_patch) wait_release_barrier<NEPI>();
-                else wait_release_barrier<G::NW>();
+                // the next pair-step's weights (and, with a 4-slot slab ring, its slabs) were issued in THIS step, i.e. after
+                // the previous patch's epilogue stores: vmcnt completes in issue order, so those stores drain here too and
+                // only the slabs issued after the weights (AHEAD - 1 pair-steps' worth) may stay in flight
+                wait_release_barrier<G::NW>();
             }
             {
                 const int u = t + 3;
@@ -901,8 +910,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     using std::integral_constant;
     const int sbx = 127 - p.x_exp, sbg = 127 - p.g_exp;
     for (int it = 0; it < my_tiles; ++it) {
-        step(integral_constant<bool, true>{}, it == 0, sbx);      // planes 0, 1 = x
-        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, false, sbg);
+        step(integral_constant<bool, true>{}, sbx);               // planes 0, 1 = x
+        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, sbg);
         epilogue(it);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

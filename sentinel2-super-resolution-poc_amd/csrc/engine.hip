@@ -44,9 +44,12 @@ struct Workspace {
     size_t bytes = 0;
     // LR tensors (blocked-16 fp16 / blocked-8 fp32, see s2sr_internal.h)
     char *P0 = nullptr;                  // input, 1 block
-    char *D[2] = {nullptr, nullptr};     // dense-block tensors, 12 blocks: [x(4) | x1 | x2 | x3 | x4]
+    char *D[3] = {nullptr, nullptr, nullptr};   // dense-block tensors, 12 blocks: [x(4) | x1 | x2 | x3 | x4]; three of them rotate
+                                         // through an RRDB (rdb k reads D[k], writes the next x into D[(k+1)%3]), so the
+                                         // RRDB's input D[0] is still there when rdb3's conv5 needs it as the skip
     char *U0 = nullptr;                  // 4 blocks
-    char *T = nullptr;                   // trunk lo (fp16, 4 blocks)
+    char *T = nullptr;                   // trunk lo (fp16, 4 blocks) = Tr[0]
+    char *Tr[3] = {nullptr, nullptr, nullptr};  // trunk lo of D[0..2]
     float *R = nullptr, *F = nullptr;    // fp32 RRDB skip / global skip (8 blocks of 8)
     // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
@@ -107,6 +110,8 @@ struct s2sr_handle {
     hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
     std::vector<hipEvent_t> group_done;
     // hipGraph replay of repeated groups
+    bool fp8_hp_tail = false;     // S2SR_PREC_FP8: the six head / tail convs in plain fp16 (their ~2e-3 is below the trunk's e4m3
+                                  // error) unless S2SR_FP8_TAIL=hp asks for the split-operand forms
     int fp8_x_exp = 4, fp8_g_exp = 6;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
@@ -176,7 +181,7 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     Workspace& w = h->ws;
     const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
-    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || fp8;   // split-operand head / tail convs
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || (fp8 && h->fp8_hp_tail);   // split-operand head / tail convs
     if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp && w.fp8 == fp8) return S2SR_OK;
     if (w.base) {
         HIPCHK(h, hipDeviceSynchronize());
@@ -193,8 +198,9 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
     const size_t g = (size_t)G;
     const size_t nd = fp8 ? 0 : 12;     // the fp16 dense tensors are not used by the fp8 trunk
-    const size_t oP0 = take(g * w.blk1), oD0 = take(g * nd * w.blk1), oD1 = take(g * nd * w.blk1),
-                 oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oR = take(g * 8 * w.blk1),
+    const size_t oP0 = take(g * w.blk1), oD0 = take(g * nd * w.blk1), oD1 = take(g * nd * w.blk1), oD2 = take(g * nd * w.blk1),
+                 oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oT1 = take(g * (fp8 ? 0 : 4) * w.blk1),
+                 oT2 = take(g * (fp8 ? 0 : 4) * w.blk1), oR = take(g * 8 * w.blk1),
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
     size_t oU0l = 0, oU1l = 0, oU2l = 0, oU3l = 0;
@@ -213,8 +219,8 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
     HIPCHK(h, hipDeviceSynchronize());
-    w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.U0 = w.base + oU0;
-    w.T = w.base + oT; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
+    w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.D[2] = w.base + oD2; w.U0 = w.base + oU0;
+    w.T = w.base + oT; w.Tr[0] = w.T; w.Tr[1] = w.base + oT1; w.Tr[2] = w.base + oT2; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
     if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; w.T8 = w.base + oT8; }
     if (fp8) {
@@ -287,7 +293,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_LAST) bytes += px * 3.0 * ((p.out_u8 ? 1.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0));
     else bytes += px * cw.cout * 2.0;
     if (epi == EPI_RDB5) bytes += px * 64 * 4.0;          // lo: fp16 read + write
-    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * 12.0;    // lo r/w + R fp32 r/w
+    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * (p.xh_skip ? 8.0 : 12.0);    // lo r/w + RRDB skip: fp16 pair read (trunk kernel) or fp32 R r/w
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
@@ -377,6 +383,27 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
                 cur ^= 1;
             }
         trunk_hi = w.Xh[0]; trunk_hi_img = 4 * w.blk1; trunk_lo = w.Tz;
+    } else if (h->trunk_w4) {
+        // one-wave-per-SIMD trunk kernel: rdb r of every RRDB reads D[r] / Tr[r] and writes the next trunk (x, lo) into
+        // D[(r+1)%3] / Tr[(r+1)%3]; rdb3's conv5 takes the RRDB skip from (D[0] x blocks, Tr[0]) -- still the RRDB's
+        // input -- and overwrites exactly those pixels (same lane reads, then writes; nobody else touches D[0] then)
+        for (int blk = 0; blk < nb; ++blk)
+            for (int r = 0; r < 3; ++r) {
+                const int nx = (r + 1) % 3;
+                for (int k = 1; k <= 4; ++k) {
+                    ConvParams p = b;
+                    p.src = w.D[r]; p.src_img = 12 * w.blk1;
+                    p.dst = w.D[r] + (size_t)(4 + 2 * (k - 1)) * w.blk1; p.dst_img = 12 * w.blk1;
+                    if ((rc = run_conv(h, st, F_RDB14, h->convs[ci++], p, EPI_LRELU, false))) return rc;
+                }
+                ConvParams p = b;
+                p.src = w.D[r]; p.src_img = 12 * w.blk1;
+                p.dst = w.D[nx]; p.dst_img = 12 * w.blk1;
+                p.xh_in = w.Tr[r]; p.T = w.Tr[nx];
+                if (r == 2) { p.xh_skip = w.D[0]; p.xh_img = 12 * w.blk1; p.lo_skip = w.Tr[0]; }
+                if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
+            }
+        trunk_hi = w.D[0]; trunk_hi_img = 12 * w.blk1; trunk_lo = w.Tr[0];
     } else {
         for (int blk = 0; blk < nb; ++blk)
             for (int r = 0; r < 3; ++r) {
@@ -442,10 +469,11 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
 
 int group_size(const s2sr_handle* h, int B, int H, int W) {
     int g = h->cfg.group > 0 ? h->cfg.group : 16;
-    // keep the workspace modest (<= ~24 GiB)
-    const double per_img = (double)padded(H) * padded(W) * 1568.0 + (double)padded(2 * H) * padded(2 * W) * 128.0 +
-                           (double)padded(4 * H) * padded(4 * W) * 256.0;
-    while (g > 1 && per_img * g > 24.0 * 1024 * 1024 * 1024) --g;
+    // keep the workspace within a quarter of the 288 GB: bytes per LR pixel 32 + 3*384 (dense) + 128 + 3*128 (lo) + 2*256
+    // (fp32 skips) + 2*128 (hp planes); 2x and 4x tensors with their correction planes
+    const double per_img = (double)padded(H) * padded(W) * 2500.0 + (double)padded(2 * H) * padded(2 * W) * 256.0 +
+                           (double)padded(4 * H) * padded(4 * W) * 512.0;
+    while (g > 1 && per_img * g > 64.0 * 1024 * 1024 * 1024) --g;
     if (g > B) g = B;
     return g < 1 ? 1 : g;
 }
@@ -579,6 +607,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     }
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
@@ -644,7 +673,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     const float* pw = blob;
     std::vector<char> tmp;
     const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
-    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || fp8;
+    const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || (fp8 && h->fp8_hp_tail);
     const size_t nconv = specs.size();
     size_t idx = 0;
     for (const ConvSpec& s : specs) {
@@ -662,7 +691,7 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
         cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold || f8) ? 0x2 : 0x0;
         cw.f8 = f8;
-        const bool f8trunk = fp8 && !split;             // the 345 RDB convs
+        const bool f8trunk = fp8 && idx >= 1 && idx + 5 < nconv;   // the 345 RDB convs
         const size_t wb = f8trunk ? conv_wpack_bytes_f8(s.cin, s.cout) : conv_wpack_bytes_seg(s.cin, s.cout, nseg);
         tmp.resize(wb);
         if (f8trunk) {

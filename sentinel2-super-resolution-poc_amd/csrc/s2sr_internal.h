@@ -75,7 +75,10 @@ struct ConvParams {
     // pixel, the geometry of an fp16 block-16 plane); nstage = planes per patch padded to an even count, seg_len = real
     // planes (a phantom plane re-reads plane 0 against zero weights); the trunk itself is carried in fp16:
     const char* xh_in;       // conv5: trunk x (fp16 blocked-16, 4 blocks) -- the residual operand
-    const char* xh_skip;     // conv5 of rdb3: the RRDB's input x (fp16, 4 blocks)
+    const char* xh_skip;     // conv5 of rdb3: the RRDB's input x (fp16, 4 blocks).  Also used by conv_trunk_f16 (fp16 modes):
+                             // there the RRDB skip is the fp16 PAIR (xh_skip, lo_skip) of the trunk at the RRDB's input, read
+                             // in place of the fp32 R tensor (-256 B per pixel: no R store, two 8-B halves instead of 16 B)
+    const char* lo_skip;     // ... its lo half (fp16, 4 blocks, image stride as T)
     char* xh_out;            // conv5: new trunk x (fp16, 4 blocks); may alias xh_skip (same lane reads, then writes)
     uint64_t xh_img;         // bytes between images of the three
     const int32_t* wscale;   // [64] E8M0 bytes 127 - k_co of the per-output-channel weight scales 2^k_co
