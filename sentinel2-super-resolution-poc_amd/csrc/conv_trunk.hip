@@ -549,7 +549,7 @@ struct TG8 {
     static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
     static constexpr int PI = PLANE / 1024;                     // slab DMA pieces per plane
     static constexpr int WI = 9 * CT;                           // weight DMA pieces per plane
-    static constexpr int PWS = (2 * PI + WAVES - 1) / WAVES;    // slab DMA instructions per wave and pair-step
+    static constexpr int PWS = 2 * (PI / WAVES);                // slab DMA instructions per wave and pair-step
     static constexpr int PWW = (2 * WI + WAVES - 1) / WAVES;    // weight DMA instructions per wave and pair-step
     static constexpr int ND = PWS + PWW;
     static constexpr int WBYTES = 2 * WI * 1024;                // one weight slot (two planes)
@@ -560,7 +560,8 @@ struct TG8 {
     static constexpr int AHEAD = RS / 2 - 1;                    // pair-steps the slab DMA runs ahead
     static constexpr int NW = (AHEAD - 1) * PWS;                // DMA instructions that may stay in flight at a barrier
     static_assert(RS % 2 == 0 && RS >= 4, "slab ring holds whole pairs");
-    static_assert((2 * PI) % WAVES == 0, "slab pieces split evenly over the waves");
+    static_assert(PI % WAVES == 0, "each plane's slab pieces split evenly over the waves (piece -> plane is then compile-time)");
+    static constexpr int PWP = PI / WAVES;                       // slab DMA instructions per wave and PLANE
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
 };
@@ -593,11 +594,12 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) sa[ct] = p.wscale[ct * 32 + pcol];
 
-    // ---- per-lane global offsets of my DMA pieces.  Slab piece i = wave + 4*sl of the pair: plane i / PI, piece i % PI.
-    uint32_t loffS[G::PWS];
+    // ---- per-lane global offsets of my DMA pieces.  Slab: instruction sl of a pair-step moves piece wave + 4*(sl % PWP) of
+    // plane sl / PWP -- which plane is a compile-time property of sl, so the loop carries no selects.
+    uint32_t loffS[G::PWP];
 #pragma unroll
-    for (int sl = 0; sl < G::PWS; ++sl) {
-        const int jj = (wave + sl * 4) % G::PI;
+    for (int sl = 0; sl < G::PWP; ++sl) {
+        const int jj = wave + sl * 4;
         const int i = jj * 64 + lane;
         int q = i >> 1;
         if (q >= G::SPX) q = 0;
@@ -605,7 +607,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         const int h2 = (i & 1) ^ ((rx >> 3) & 1);
         loffS[sl] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
     }
-    const uint32_t lane16 = (uint32_t)lane * 16;
+    const uint32_t lane16w = (uint32_t)lane * 16 + (uint32_t)wave * 1024;   // weight piece `wave` of my lane
 
     // ---- two DMA cursors over my pair-steps: slabs (AHEAD steps ahead) and weights (one step ahead); both stay on the
     // last pair-step of the last patch once they get there
@@ -614,6 +616,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     const char* sA = nullptr;   // slab sources of the pair under the slab cursor
     const char* sB = nullptr;
     const char* wS = nullptr;   // weights of the pair under the weight cursor
+    bool ph_slab = false, ph_wts = false;   // the pair's second plane is a phantom (slab cursor / weight cursor)
     auto advance = [&](Cur& c) __attribute__((always_inline)) {
         if (++c.st == NSTEP) {
             if (c.it + 1 < my_tiles) { c.st = 0; ++c.it; }
@@ -629,28 +632,41 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
             cs.pbase = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
         }
         const int pa = 2 * cs.st, pb = 2 * cs.st + 1;
-        sA = cs.pbase + (size_t)(pa < nreal ? pa : 0) * sblk;
+        sA = cs.pbase + (size_t)pa * sblk;                       // nreal >= 1 and pairs start on even planes: plane A is always real
         sB = cs.pbase + (size_t)(pb < nreal ? pb : 0) * sblk;
+        // a phantom plane (odd plane counts) is filled from ONE 16-byte piece of plane 0 (stored e4m3 bytes are never NaN:
+        // the producers clamp before converting), so each of its DMA instructions is a single cache-line request instead
+        // of sixteen: finite bytes against zero weights
+        ph_slab = pb >= nreal;
         advance(cs);
     };
     auto wts_next = [&]() __attribute__((always_inline)) {
         wS = (const char*)p.wpack + (size_t)cw.st * G::WBYTES;
+        ph_wts = 2 * cw.st + 1 >= nreal;                         // second plane's weight block is the all-zero phantom block
         advance(cw);
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-    // slab piece sl of the pair whose first plane sits in ring slot `slot0` (the second in slot0 + 1, wrapping)
-    auto dma_slab = [&](int sl, uint32_t slot0) __attribute__((always_inline)) {
-        const int i = wave + sl * 4;
-        const bool second = i >= G::PI;
-        const int jj = second ? i - G::PI : i;
-        uint32_t slot = slot0 + (second ? 1u : 0u);
-        if (slot == (uint32_t)RS) slot = 0;
-        glds16<false>(second ? sB : sA, loffS[sl], lds0 + slot * G::PLANE + (uint32_t)jj * 1024);
+    // DMA targets of the current pair-step, set once per step: M0 values of my first piece in slab slot A / B and in the
+    // weight slot (everything else about a piece is an immediate)
+    uint32_t mA = 0, mB = 0, mW = 0;
+    auto dma_targets = [&](uint32_t slot0, uint32_t wslot) __attribute__((always_inline)) {
+        uint32_t s1 = slot0 + 1;
+        if (s1 == (uint32_t)RS) s1 = 0;
+        mA = lds0 + slot0 * G::PLANE + (uint32_t)wave * 1024;
+        mB = lds0 + s1 * G::PLANE + (uint32_t)wave * 1024;
+        mW = lds0 + G::WOFF + wslot * G::WBYTES + (uint32_t)wave * 1024;
     };
-    auto dma_wts = [&](int sl, uint32_t wslot) __attribute__((always_inline)) {
-        int i = wave + sl * 4;
-        if (i > 2 * G::WI - 1) i = 2 * G::WI - 1;                // padding slot: the last piece again
-        glds16<false>(wS, lane16 + (uint32_t)i * 1024, lds0 + G::WOFF + wslot * G::WBYTES + (uint32_t)i * 1024);
+    auto dma_slab = [&](int sl) __attribute__((always_inline)) {        // sl is a compile-time constant at every call
+        const bool second = sl >= G::PWP;
+        const int k = second ? sl - G::PWP : sl;
+        glds16<false>(second ? sB : sA, (second && ph_slab) ? 0u : loffS[k], (second ? mB : mA) + (uint32_t)k * 4096);
+    };
+    auto dma_wts = [&](int sl) __attribute__((always_inline)) {
+        // piece i = wave + 4*sl of the pair's 2*WI KiB; past the end (last sl only): the last piece again
+        const bool over = (sl * 4 + 3 > 2 * G::WI - 1) && (wave + sl * 4 > 2 * G::WI - 1);
+        const uint32_t back = over ? (uint32_t)(wave + sl * 4 - (2 * G::WI - 1)) * 1024 : 0u;
+        const bool zero = ph_wts && (sl * 4 >= G::WI || (sl * 4 + 3 >= G::WI && wave + sl * 4 >= G::WI));   // piece of the phantom's zero block
+        glds16<false>(wS, zero ? (uint32_t)(G::WI * 1024) : lane16w + (uint32_t)sl * 4096 - back, mW + (uint32_t)sl * 4096 - back);
     };
 
     // ---- fragment addresses: per-lane base + immediate.  b0 / b1 = logical 16-B halves 0 / 1 of pixel (row, pcol + dx)
@@ -684,16 +700,22 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     uint32_t cur_w = 0;           // weight slot of the current pair
     {
         slab_next();              // slabs of pair-step 0
+        dma_targets(0, 0);
 #pragma unroll
-        for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl, 0);
-        wts_next();               // weights of pair-step 0
+        for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl);
+        wts_next();               // weights of pair-steps 0 and 1
 #pragma unroll
-        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl, 0);
+        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
+        wts_next();
+        dma_targets(0, 1);
+#pragma unroll
+        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
 #pragma unroll
         for (int a = 1; a < G::AHEAD; ++a) {
             slab_next();
+            dma_targets((uint32_t)(2 * a), 1);
 #pragma unroll
-            for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl, (uint32_t)(2 * a));
+            for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl);
         }
     }
     wait_release_barrier<G::NW>();
@@ -713,7 +735,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     }
 
     // One pair-step.  FIRST: first of a patch.  `sb` = E8M0 activation scale of this pair (x planes / growth planes).
-    auto step = [&](auto first_tag, int sb) __attribute__((always_inline)) {
+    auto step = [&](auto first_tag, bool first_patch, int sb) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         uint32_t next_slot = cur_slot + 2;
         if (next_slot >= (uint32_t)RS) next_slot -= RS;
@@ -722,16 +744,20 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         while (dma_slot >= (uint32_t)RS) dma_slot -= RS;
         const uint32_t ls = lane_slab_of(cur_slot), lsn = lane_slab_of(next_slot);
         const uint32_t wo = cur_w * G::WBYTES, won = (cur_w ^ 1) * G::WBYTES;
-        wts_next();
         slab_next();
+        dma_targets(dma_slot, cur_w);
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
             if (t == G::T - 3) {
-                // the next pair-step's weights (and, with a 4-slot slab ring, its slabs) were issued in THIS step, i.e. after
-                // the previous patch's epilogue stores: vmcnt completes in issue order, so those stores drain here too and
-                // only the slabs issued after the weights (AHEAD - 1 pair-steps' worth) may stay in flight
-                wait_release_barrier<G::NW>();
+                // needed: the next pair-step's slabs and weights.  The weights were issued in the PREVIOUS step's tail, i.e.
+                // before a patch boundary's epilogue stores; with the 6-slot ring so were the slabs, and the stores and this
+                // step's slab DMA (one pair-step's worth) may stay in flight.  With the 4-slot ring the needed slabs are this
+                // step's own: everything drains (vmcnt completes in issue order).
+                constexpr int NEPI = (G::AHEAD >= 2) ? G::NW + CT * NP : 0;      // conv1-4 form: CT*NP plane stores per wave
+                if (FIRST && !first_patch && G::AHEAD >= 2) wait_release_barrier<NEPI>();
+                else wait_release_barrier<G::NW>();
+                wts_next();                                   // two pair-steps ahead: into the weight slot this barrier released
             }
             {
                 const int u = t + 3;
@@ -748,13 +774,15 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
                 for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = ldA(won, dy * 3, ct);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // DMA: the next pair-step's weights first, then the slabs AHEAD pair-steps ahead; all in front of the barrier step
+            // DMA: the slabs AHEAD pair-steps ahead in front of the barrier step, the weights two pair-steps ahead behind it
 #pragma unroll
-            for (int i = 0; i < G::ND; ++i)
-                if ((i * (G::T - 3)) / G::ND == t) {
-                    if (i < G::PWW) dma_wts(i, cur_w ^ 1);
-                    else dma_slab(i - G::PWW, dma_slot);
-                }
+            for (int i = 0; i < G::PWS; ++i)
+                if ((i * (G::T - 3)) / G::PWS == t) dma_slab(i);
+            if (t >= G::T - 3) {
+#pragma unroll
+                for (int i = 0; i < G::PWW; ++i)
+                    if (G::T - 3 + (i * 3) / G::PWW == t) dma_wts(i);
+            }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int np = s - dy;
@@ -910,8 +938,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     using std::integral_constant;
     const int sbx = 127 - p.x_exp, sbg = 127 - p.g_exp;
     for (int it = 0; it < my_tiles; ++it) {
-        step(integral_constant<bool, true>{}, sbx);               // planes 0, 1 = x
-        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, sbg);
+        step(integral_constant<bool, true>{}, it == 0, sbx);      // planes 0, 1 = x
+        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, false, sbg);
         epilogue(it);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -21,7 +21,7 @@ ap.add_argument("--blocks", type=int, default=23)
 ap.add_argument("--group", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--prof", type=int, default=1)
-ap.add_argument("--hp", type=int, default=0)
+ap.add_argument("--hp", type=int, default=0, help="precision: 0 fast, 1 hp, 2 fp8")
 a = ap.parse_args()
 
 e = native.Engine(num_block=a.blocks, group=a.group, precision=a.hp)

@@ -1,37 +1,67 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 csv output (kernel-trace stats + pmc passes) per kernel name."""
+"""Summarise rocprofv3 csv output of tools/prof_r02.sh per kernel: kernel-trace stats per mode, PMC sums per
+dispatch, and profiles-ready pmc_summary.json (HBM bytes per image and launch of the RDB conv kernels:
+FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, both reported in KiB)."""
 import csv
 import glob
+import json
+import re
+import subprocess
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+IMGS = 16          # images per launch in the PMC runs (tools/prof_r02.sh: --batch 16 --group 16)
 
 
 def short(n):
-    n = n.replace("s2sr::", "").replace("void ", "")
-    return n[:70]
+    n = n.replace("s2sr::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(s2sr::ConvParams\)|\(ConvParams\)", "", n)[:74]
 
 
-for f in glob.glob(f"{out}/trace/**/*kernel_stats.csv", recursive=True):
-    print("== kernel stats", f)
-    rows = list(csv.DictReader(open(f)))
-    for r in rows[:14]:
-        print(f"  {short(r['Name']):70s} calls {r['Calls']:>6s} total_ns {r['TotalDurationNs']:>12s} avg_ns {r['AverageNs']:>12s} pct {r['Percentage']}")
+for mode in ("hp", "fp8"):
+    for f in glob.glob(f"{out}/trace_{mode}/**/*kernel_stats.csv", recursive=True):
+        print(f"== kernel stats ({mode})", f)
+        for r in list(csv.DictReader(open(f)))[:16]:
+            print(f"  {short(r['Name']):74s} calls {r['Calls']:>6s} total_ns {r['TotalDurationNs']:>12s} avg_ns {r['AverageNs']:>10s} pct {r['Percentage']}")
 
-for p in sorted(glob.glob(f"{out}/pmc_*/")):
-    files = glob.glob(f"{p}/**/*counter_collection.csv", recursive=True)
-    if not files:
-        continue
-    agg = defaultdict(lambda: defaultdict(float))
-    cnt = defaultdict(lambda: defaultdict(int))
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[k][r["Counter_Name"]] += 1
-    print("== pmc", p)
-    for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:8]:
+pmc = {}
+for mode in ("hp", "fp8"):
+    per = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for p in sorted(glob.glob(f"{out}/pmc_{mode}_*/")):
+        for f in glob.glob(f"{p}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                c = per[k][r["Counter_Name"]]
+                c[0] += float(r["Counter_Value"])
+                c[1] += 1
+    print(f"== pmc ({mode}), per dispatch")
+    for k in sorted(per, key=lambda k: -per[k].get("SQ_WAVE_CYCLES", [0, 1])[0])[:8]:
         print(" ", k)
-        for c, v in agg[k].items():
-            print(f"      {c:28s} sum {v:16.0f}  per-dispatch {v / max(cnt[k][c], 1):14.0f}  (n={cnt[k][c]})")
+        for c, (v, n) in sorted(per[k].items()):
+            print(f"      {c:28s} per-dispatch {v / max(n, 1):16.0f}  (n={n})")
+    pmc[mode] = per
+
+try:
+    rev = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    rev = None
+summary = {"_meta": {"group": IMGS, "git_rev": rev, "tool": "tools/prof_r02.sh",
+                     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on tools/quick_bench.py --batch 16 --group 16; "
+                             "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B); counter units KiB"}}
+FAM = {"hp": {"rdb_conv1-4": ("conv_trunk_f16<1, 8, 3, 0", 18874368), "rdb_conv5": ("conv_trunk_f16<2, 4, 4, 1", 50331648),
+              "rdb_conv5_rrdb": ("conv_trunk_f16<2, 4, 4, 2", 67108864)},
+       "fp8": {"rdb_conv1-4": ("conv_trunk_f8<1, 4, 6, 0", 9437184), "rdb_conv5": ("conv_trunk_f8<2, 4, 4, 1", 33554432),
+               "rdb_conv5_rrdb": ("conv_trunk_f8<2, 4, 4, 2", 41943040)}}
+for mode, fams in FAM.items():
+    for fam, (pat, alg) in fams.items():
+        for k, cs in pmc.get(mode, {}).items():
+            if pat in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                fk = cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1]
+                wk = cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1]
+                ent = {"kernel": k, "images_per_launch": IMGS, "fetch_kib_raw": round(fk), "write_kib": round(wk),
+                       "hbm_bytes_per_image": round((2 * fk + wk) * 1024 / IMGS), "algorithmic_bytes_per_image_mean": alg}
+                summary[("" if mode == "hp" else "fp8:") + fam] = ent
+json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
+print("== pmc_summary.json")
+print(json.dumps(summary, indent=1))
