@@ -36,6 +36,10 @@
 
 #include "s2sr_internal.h"
 
+#ifndef S2SR_F16_BIASC
+#define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
+#endif
+
 namespace s2sr {
 
 namespace {
@@ -115,6 +119,12 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, const f16x8& a, const f16x
 __device__ __forceinline__ void mfma_first(f32x16& acc, const f16x8& a, const f16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
 }
+
+// first MFMA of a patch with the bias vector (AGPRs, constant for the whole kernel) as C: the bias costs no instruction
+__device__ __forceinline__ void mfma_first_bias(f32x16& acc, const f16x8& a, const f16x8& b, const f32x16& bias) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(acc) : "v"(a), "v"(b), "a"(bias));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int N>
 __device__ __forceinline__ void wait_release_barrier() {
@@ -218,6 +228,20 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     char* const trash = p.trash + (size_t)tid * 16;
 
     f32x16 acc[CT][NP];
+    // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
+    // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
+    constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
+    f32x16 bacc[kBiasC ? CT : 1];
+    if (kBiasC) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = p.bias[ct * 32 + 8 * g + 4 * hh + i];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+    }
     f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
     f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
 
@@ -297,8 +321,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                 if (np < 0 || np >= NP) continue;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    if (FIRST && dx == 0 && dy == 0) mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
-                    else mfma_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                    if (FIRST && dx == 0 && dy == 0) {
+                        if (kBiasC) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
+                        else mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                    } else mfma_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -394,12 +420,21 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
+                    if (EPI == EPI_LRELU && !kBiasC) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
-                    if (EPI == EPI_LRELU) {
+                        for (int i = 0; i < 4; ++i) v[i] = lrelu(__fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]));
+                    } else if (EPI == EPI_LRELU) {
+                        // LeakyReLU on pairs (v_pk_mul_f32 / v_pk_max_f32): the bias is already in the accumulator
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            f32x2 x;
+                            x[0] = acc[ct][np][4 * g + 2 * h2]; x[1] = acc[ct][np][4 * g + 2 * h2 + 1];
+                            const f32x2 y = __builtin_elementwise_max(x, x * 0.2f);
+                            v[2 * h2] = y[0]; v[2 * h2 + 1] = y[1];
+                        }
                     } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
                         // t = hi + lo (exact in fp32); hi was captured from LDS: block ct*2 + (g>>1), half g&1
                         const f32x4 th = half4_to_float(hi_cap[kTrunk ? (ct * 2 + (g >> 1)) & 3 : 0][kTrunk ? np : 0][g & 1]);
                         const f32x4 tl = half4_to_float(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
@@ -539,6 +574,10 @@ __device__ __forceinline__ void mfma8_acc(f32x16& acc, const v8i& a, const v8i& 
 }
 __device__ __forceinline__ void mfma8_first(f32x16& acc, const v8i& a, const v8i& b, int sa, int sb) {
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+
+__device__ __forceinline__ void mfma8_first_bias(f32x16& acc, const v8i& a, const v8i& b, int sa, int sb, const f32x16& bias) {
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %5, %3, %4 op_sel_hi:[0,0,0]" : "=&a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb), "a"(bias));
 }
 
 template <int CT_, int NP_, int RS_>
@@ -682,6 +721,18 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     char* const trash = p.trash + (size_t)tid * 16;
 
     f32x16 acc[CT][NP];
+    constexpr bool kBiasC = (EPI == EPI_LRELU);     // see conv_trunk_f16
+    f32x16 bacc[kBiasC ? CT : 1];
+    if (kBiasC) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = p.bias[ct * 32 + 8 * g + 4 * hh + i];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+    }
     v8i acol[3][3][CT];
     v8i breg[6];
     auto ldA = [&](uint32_t woff, int tap, int ct) __attribute__((always_inline)) -> v8i {
@@ -789,8 +840,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
                 if (np < 0 || np >= NP) continue;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    if (FIRST && dx == 0 && dy == 0) mfma8_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
-                    else mfma8_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
+                    if (FIRST && dx == 0 && dy == 0) {
+                        if (kBiasC) mfma8_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb, bacc[kBiasC ? ct : 0]);
+                        else mfma8_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
+                    } else mfma8_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -887,12 +940,25 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
                     if (EPI == EPI_LRELU) {
+                        // bias already in the accumulator; scale, LeakyReLU and both clamps in 4 instructions per pair:
+                        // x = a*s, t = a*(0.2 s) (v_pk_mul_f32), y = max3(x, t, -448), y = min(y, 448)
+                        float y[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = lrelu(v[i]);
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            f32x2 a;
+                            a[0] = acc[ct][np][4 * g + 2 * h2]; a[1] = acc[ct][np][4 * g + 2 * h2 + 1];
+                            const f32x2 x = a * oscale, t = a * (0.2f * oscale);
+                            y[2 * h2] = fminf(__builtin_fmaxf(__builtin_fmaxf(x[0], t[0]), -448.0f), 448.0f);
+                            y[2 * h2 + 1] = fminf(__builtin_fmaxf(__builtin_fmaxf(x[1], t[1]), -448.0f), 448.0f);
+                        }
+                        int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+                        q8[g] = (uint32_t)w;
+                        continue;
                     } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
                         const f32x4 th = half4_to_float(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {

@@ -97,6 +97,19 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
+def _mapped_hip_runtimes() -> set:
+    """Real paths of every libamdhip64 mapped into this process (Linux; empty when /proc is not readable)."""
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    out.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return out
+
+
 def load_library():
     """dlopen libs2sr.so and attach prototypes.  Raises if it is not built: no fallback."""
     global _lib
@@ -105,14 +118,23 @@ def load_library():
     if not LIB_PATH.exists():
         raise S2srError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"or `make -C {LIB_PATH.parent}`.  There is no CPU fallback.")
-    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime; whichever HSA runtime is mapped first
-    # serves both HIP runtimes of the process.  torch's must come first (the other order leaves
-    # torch with "No HIP GPUs are available"), so pull torch in before dlopen when it exists.
+    # ONE HIP runtime per process.  libs2sr.so is linked against `libamdhip64.so.<N>` (RUNPATH /opt/rocm/lib) and the
+    # PyTorch-ROCm wheel bundles a runtime with the same SONAME.  The dynamic loader resolves a DT_NEEDED entry against
+    # already loaded objects by SONAME first, so when torch is imported BEFORE this dlopen, libs2sr binds to torch's
+    # bundled runtime and both sides share one HIP context, one set of streams and device pointers (which is what the
+    # `*_dev` entry points and the RCCL path need).  The other order maps the system runtime first and leaves torch with
+    # "No HIP GPUs are available".  So: import torch first when it exists, then verify that exactly one libamdhip64 is
+    # mapped -- two would mean the SONAMEs diverged (e.g. a ROCm major bump on one side) and device pointers could not
+    # be shared; that is an error, not something to limp along with.
     try:
         import torch  # noqa: F401
     except ImportError:
         pass
     lib = C.CDLL(str(LIB_PATH))
+    hips = _mapped_hip_runtimes()
+    if len(hips) > 1:
+        raise S2srError(f"two HIP runtimes are mapped into this process ({sorted(hips)}): libs2sr.so and PyTorch must share one "
+                        "libamdhip64 (same SONAME) -- rebuild libs2sr.so against the ROCm major version of the torch wheel")
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)          # AttributeError here == ABI drift, let it surface
         fn.restype, fn.argtypes = res, args
