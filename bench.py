@@ -243,7 +243,7 @@ def main():
         # profiles/pmc_summary.json: FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate passes);
         # rocprofv3 cannot run inside this process, so the figure is read from the committed summary.
         traffic, traffic_source = None, None
-        imgs = min(a.group if a.group > 0 else 16, B)          # images per launch (engine group)
+        imgs = min(a.group if a.group > 0 else (32 if a.precision == "fp8" else 16), B)   # images per launch (engine group)
         pmc = REPO / "profiles" / "pmc_summary.json"
         if pmc.exists():
             try:

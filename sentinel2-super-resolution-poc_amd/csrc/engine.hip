@@ -468,7 +468,9 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
 }
 
 int group_size(const s2sr_handle* h, int B, int H, int W) {
-    int g = h->cfg.group > 0 ? h->cfg.group : 16;
+    // default group: 16 images per launch sequence; the fp8 trunk's launches are half as long, so it takes 32 (measured:
+    // 50.5 vs 51.9 ms per 32-tile step; the fp16 modes gain nothing from 32)
+    int g = h->cfg.group > 0 ? h->cfg.group : (h->cfg.precision == S2SR_PREC_FP8 ? 32 : 16);
     // keep the workspace within a quarter of the 288 GB: bytes per LR pixel 32 + 3*384 (dense) + 128 + 3*128 (lo) + 2*256
     // (fp32 skips) + 2*128 (hp planes); 2x and 4x tensors with their correction planes
     const double per_img = (double)padded(H) * padded(W) * 2500.0 + (double)padded(2 * H) * padded(2 * W) * 256.0 +
