@@ -191,6 +191,11 @@ int  s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap
 /* test hook (host only, no GPU): the OCP e4m3fn encoder the weight packer uses for the fp8
  * correction stages -- round to nearest even, saturating at +-448, NaN -> 0x7f. */
 uint8_t s2sr_debug_f32_to_e4m3(float v);
+/* test hook (host only): the fp8-trunk weight packer (S2SR_PREC_FP8).  w = [cout][cin][3][3] fp32 -> e4m3 planes of 32 input
+ * channels, padded to an even plane count with an all-zero plane: out[plane][tap][ct][16-B half][cout row 0..31][16 bytes] =
+ * e4m3(w * 2^k_co); wscale[co] (64 entries) = the E8M0 byte 127 - k_co the MFMA's scale_a operand takes. */
+size_t s2sr_debug_pack_f8_bytes(int32_t cin, int32_t cout);
+int  s2sr_debug_pack_f8(const float* w, int32_t cin, int32_t cout, uint8_t* out, int32_t* wscale);
 
 /* test hook: one 3x3 conv layer on NCHW fp32 host tensors through the production kernel
  * (upsample != 0 -> nearest-2x on load).  act: 0 none, 1 LeakyReLU(0.2). */

@@ -785,6 +785,29 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         for (int v = 0; v < 3; ++v) breg[v] = ldB(ls, 0, v);
     }
 
+    // conv5: the residual operands (the fp16 trunk coming in; for rdb3 also the RRDB's input) of the patch's own pixels are
+    // requested at the START of the patch's last pair-step, straight into AGPRs: they arrive under its MFMAs (that
+    // step's barrier drains them with everything else issued before it) instead of stalling the epilogue for an HBM round trip
+    u32x2 t_in[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
+    auto prefetch_residuals = [&](int it) __attribute__((always_inline)) {
+        const int tile = it * nwg + slot_in_round;
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+        const size_t xn = (size_t)n * p.xh_img;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const size_t opix = (size_t)(ty * G::TH + wave * NP + np + 1) * p.Wp + (tx * G::TW + pcol + 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const size_t off = xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix * 32 + (g & 1) * 16 + hh * 8;
+                    t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g] = asm_load8(p.xh_in + off);
+                }
+        }
+    };
+
     // One pair-step.  FIRST: first of a patch.  `sb` = E8M0 activation scale of this pair (x planes / growth planes).
     auto step = [&](auto first_tag, bool first_patch, int sb) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -889,48 +912,41 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t xn = (size_t)n * p.xh_img;
-        u32x2 t_in[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
-        u32x2 r_in[EPI == EPI_RDB5_RRDB ? CT : 1][4];
         if (kTrunk) {
+            // the prefetched residuals: everything issued after them in the last pair-step may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::ND < 63 ? G::ND : 63) : "memory");
 #pragma unroll
             for (int np = 0; np < NP; ++np)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
-                            asm_load8(p.xh_in + xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
-            if (EPI == EPI_RDB5) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int np = 0; np < NP; ++np)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) asm_land(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                    for (int g = 0; g < 4; ++g) asm_land(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // rdb3: the RRDB's input per output row (all rows at once would need 64 more AGPRs than there are); row np + 1 is
+        // requested before row np is worked on
+        u32x2 r_in[EPI == EPI_RDB5_RRDB ? 2 : 1][EPI == EPI_RDB5_RRDB ? CT : 1][4];
+        auto load_skip = [&](int np) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    r_in[EPI == EPI_RDB5_RRDB ? np & 1 : 0][EPI == EPI_RDB5_RRDB ? ct : 0][g] =
+                        asm_load8(p.xh_skip + xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
+        };
+        if (EPI == EPI_RDB5_RRDB) load_skip(0);
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             if (EPI == EPI_RDB5_RRDB) {
+                // row np's skip was requested one row ago: wait for it (the stores of row np - 1 and the request of row
+                // np + 1 are younger and stay in flight), then tie it down
+                if (np + 1 < NP) load_skip(np + 1);
+                if (np + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CT * 4 + (np > 0 ? CT * 3 : 0)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(np > 0 ? CT * 3 : 0) : "memory");
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g] =
-                            asm_load8(p.xh_skip + xn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        asm_land(r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-                        if (np == 0) {
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) asm_land(t_in[kTrunk ? ct : 0][kTrunk ? q : 0][g]);
-                        }
-                    }
+                    for (int g = 0; g < 4; ++g) asm_land(r_in[EPI == EPI_RDB5_RRDB ? np & 1 : 0][EPI == EPI_RDB5_RRDB ? ct : 0][g]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -964,7 +980,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
                         for (int i = 0; i < 4; ++i) {
                             v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), th[i]);
                             if (EPI == EPI_RDB5_RRDB) {
-                                const f32x4 rr = half4_to_float(r_in[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                                const f32x4 rr = half4_to_float(r_in[EPI == EPI_RDB5_RRDB ? np & 1 : 0][EPI == EPI_RDB5_RRDB ? ct : 0][g]);
                                 v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), rr[i]);
                             }
                         }
@@ -1005,7 +1021,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     const int sbx = 127 - p.x_exp, sbg = 127 - p.g_exp;
     for (int it = 0; it < my_tiles; ++it) {
         step(integral_constant<bool, true>{}, it == 0, sbx);      // planes 0, 1 = x
-        for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, false, sbg);
+        for (int st = 1; st < NSTEP; ++st) {
+            if (kTrunk && st == NSTEP - 1) prefetch_residuals(it);   // conv5: NSTEP == 3 (host)
+            step(integral_constant<bool, false>{}, false, sbg);
+        }
         epilogue(it);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1038,6 +1057,7 @@ hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
     }
     // operand shapes the kernel's indexing assumes
     if (p.nstage < 2 || p.nstage > 6 || (p.nstage & 1) || p.seg_len < 1 || p.seg_len > p.nstage) return hipErrorInvalidValue;
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && p.nstage < 4) return hipErrorInvalidValue;   // the residual prefetch rides on a later pair-step than the first
     if (p.sHp != p.Hp || p.sWp != p.Wp) return hipErrorInvalidValue;
     if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;
     if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash || !p.wscale) return hipErrorInvalidValue;

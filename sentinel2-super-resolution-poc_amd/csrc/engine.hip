@@ -1232,6 +1232,17 @@ int s2sr_synchronize(s2sr_handle* h) {
 
 uint8_t s2sr_debug_f32_to_e4m3(float v) { return f32_to_e4m3(v); }
 
+size_t s2sr_debug_pack_f8_bytes(int32_t cin, int32_t cout) {
+    if (cin <= 0 || cout <= 0 || cout > 64) return 0;
+    return conv_wpack_bytes_f8(cin, cout);
+}
+
+int s2sr_debug_pack_f8(const float* w, int32_t cin, int32_t cout, uint8_t* out, int32_t* wscale) {
+    if (!w || !out || !wscale || cin <= 0 || cout <= 0 || cout > 64) return S2SR_E_INVALID;
+    pack_conv_weights_f8(w, cin, cout, out, wscale);
+    return S2SR_OK;
+}
+
 int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W, const float* weight,
                     const float* bias, int32_t Cout, int32_t upsample, int32_t act, float* y) {
     if (!h || !x || !weight || !bias || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 64 || H <= 0 || W <= 0)

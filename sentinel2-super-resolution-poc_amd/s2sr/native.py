@@ -83,6 +83,8 @@ _PROTOS = {
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
     "s2sr_synchronize": (C.c_int, [C.c_void_p]),
     "s2sr_debug_f32_to_e4m3": (C.c_uint8, [C.c_float]),
+    "s2sr_debug_pack_f8_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "s2sr_debug_pack_f8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "s2sr_warp_bilinear_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_base_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]),

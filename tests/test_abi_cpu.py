@@ -82,3 +82,69 @@ def test_e4m3_encoder_matches_torch():
     assert bad.size == 0, [(float(vals[i]), hex(got[i]), hex(want[i])) for i in bad[:5]]
     assert lib.s2sr_debug_f32_to_e4m3(1e9) == 0x7E and lib.s2sr_debug_f32_to_e4m3(-1e9) == 0xFE   # saturate, never NaN
     assert lib.s2sr_debug_f32_to_e4m3(float("nan")) == 0x7F
+
+
+def _e4m3_decode(b: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn bytes -> float (bias 7, subnormals, no infinities, 0x7f/0xff = NaN)."""
+    b = b.astype(np.int32)
+    sign = np.where(b & 0x80, -1.0, 1.0)
+    e = (b >> 3) & 0xF
+    m = b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (8 + m) * 2.0 ** (e - 10))
+    v = np.where((b & 0x7F) == 0x7F, np.nan, v)
+    return sign * v
+
+
+def test_fp8_trunk_weight_packer_host():
+    """pack_conv_weights_f8 (S2SR_PREC_FP8), host side: per-output-channel power-of-two scales put each row's maximum
+    into e4m3's top binade, the packed bytes decode back to the weights within e4m3's half-ulp, odd plane counts get an
+    all-zero phantom plane, and the byte order is [plane][tap][ct][16-B half][cout row][16 channels]."""
+    lib = native.load_library()
+    rng = np.random.default_rng(5)
+    for cin, cout in ((64, 32), (96, 32), (160, 32), (192, 64)):
+        w = (rng.standard_normal((cout, cin, 3, 3)) * rng.uniform(1e-3, 2.0, size=(cout, 1, 1, 1))).astype(np.float32)
+        w[3, 5, 1, 1] = 0.0
+        nb = lib.s2sr_debug_pack_f8_bytes(cin, cout)
+        nreal, ct = cin // 32, (cout + 31) // 32
+        npad = (nreal + 1) & ~1
+        assert nb == npad * 9 * ct * 1024
+        out = np.zeros(nb, np.uint8)
+        ws = np.zeros(64, np.int32)
+        assert lib.s2sr_debug_pack_f8(w.ctypes.data, cin, cout, out.ctypes.data, ws.ctypes.data) == 0
+        k = 127 - ws[:cout]
+        m = np.abs(w).reshape(cout, -1).max(axis=1)
+        top = m * 2.0 ** k
+        assert np.all((top >= 224) & (top < 448)), (top.min(), top.max())
+        assert np.all(ws[cout:] == 127)
+        dec = _e4m3_decode(out).reshape(npad, 9, ct, 2, 32, 16)
+        assert not np.isnan(dec).any()
+        # [plane][tap][ct][h16][row][j] -> w[co = ct*32 + row][ci = 32*plane + 16*h16 + j][tap]
+        got = dec.transpose(2, 4, 0, 3, 5, 1).reshape(ct * 32, npad * 32, 9)[:cout]
+        if npad > nreal:
+            assert np.all(got[:, nreal * 32:] == 0) and np.all(out.reshape(npad, -1)[nreal:] == 0)
+        scaled = w.reshape(cout, cin, 9) * (2.0 ** k)[:, None, None]
+        err = np.abs(got[:, :cin] - scaled)
+        # half an ulp of e4m3 at the value's binade (3 mantissa bits), 2^-10 in the subnormal range
+        ulp = np.maximum(2.0 ** (np.floor(np.log2(np.maximum(np.abs(scaled), 2.0 ** -6))) - 3), 2.0 ** -9)
+        assert np.all(err <= ulp / 2 + 1e-12)
+        assert got[3, 5, 4] == 0
+
+
+def test_hidden_asm_loads_are_not_touched_before_their_wait(tmp_path):
+    """The conv kernels' residual loads are inline asm (invisible to hipcc's waitcnt pass); tools/check_asm_loads.py reads
+    the device assembly and fails on any instruction that touches such a load's destination registers before the wait that
+    covers it -- the pattern behind r01's faulting 4-wave variant.  Compiles both conv sources to assembly (~1.5 min)."""
+    import os
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    csrc = REPO / "sentinel2-super-resolution-poc_amd" / "csrc"
+    for src in ("conv_trunk.hip", "conv3x3.hip"):
+        asm = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
+                        "--cuda-device-only", str(csrc / src), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_loads.py"), str(asm)], capture_output=True, text=True)
+        assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:]
+        assert asm.read_text().count("global_load_dwordx2 a[") + asm.read_text().count("global_load_dwordx4 a[") > 0

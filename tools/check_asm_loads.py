@@ -24,14 +24,18 @@ def regs(tok):
 
 
 def check(path):
+    """A hidden load is complete once an `s_waitcnt vmcnt(N)` has executed with at most N vector-memory operations
+    issued after it (vmcnt completes in issue order); until then nothing may touch its destination registers."""
     bad = 0
     kernel = None
-    pending = {}          # reg -> line number of the load
+    pending = {}          # reg -> (line of the load, index of the load in the vector-memory stream)
+    nvm = 0               # vector-memory operations issued so far in this kernel (straight-line count; loops only
+                          # make the real distance larger or equal within one trip)
     in_asm = False
     for ln, line in enumerate(open(path), 1):
         t = line.strip()
-        if t.endswith(":") and t.startswith("_Z"):
-            kernel, pending = t[:-1], {}
+        if t.startswith("_Z") and ":" in t and not t.startswith("_ZZ"):
+            kernel, pending, nvm = t.split(":")[0], {}, 0
         if t.startswith(";;#ASMSTART"):
             in_asm = True
             continue
@@ -41,13 +45,16 @@ def check(path):
         if not t or t.startswith(";") or t.startswith("."):
             continue
         toks = re.findall(r"[av]\[\d+:\d+\]|[av]\d+", t)
+        is_vm = bool(re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", t))
         if in_asm and t.startswith("global_load_dword") and "lds" not in t:
-            dst = regs(toks[0]) if toks else set()
-            for r in dst:
-                pending[r] = ln
+            nvm += 1
+            for r in (regs(toks[0]) if toks else set()):
+                pending[r] = (ln, nvm)
             continue
-        if "s_waitcnt" in t and re.search(r"vmcnt\(0\)", t):
-            pending = {}
+        m = re.search(r"vmcnt\((\d+)\)", t) if "s_waitcnt" in t else None
+        if m:
+            n = int(m.group(1))
+            pending = {r: v for r, v in pending.items() if nvm - v[1] < n}      # still among the n youngest
             continue
         if pending:
             used = set()
@@ -56,7 +63,9 @@ def check(path):
             hit = used & set(pending)
             if hit:
                 bad += 1
-                print(f"{path}:{ln}: {kernel}: `{t}` touches {sorted(hit)} loaded at line {min(pending[r] for r in hit)} before vmcnt(0)")
+                print(f"{path}:{ln}: {kernel}: `{t}` touches {sorted(hit)} loaded at line {min(pending[r][0] for r in hit)} before its vmcnt")
+        if is_vm:
+            nvm += 1
     return bad
 
 
