@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = *(const f32x4*)(smem + G::BIAS_OFF + (ct * 32 + 8 * g + 4 * hh) * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = v[i];
+                for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = kTrunk ? v[i] * 0.2f : v[i];
             }
         bool ok[NP];
         size_t opix[NP];
@@ -973,24 +973,35 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
                         q8[g] = (uint32_t)w;
                         continue;
                     } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
+                        // v = (acc + bias) * 0.2 + t [* 0.2 + skip] on pairs: acc * 0.2 + (0.2 * bias + t) is one v_pk_add_f32 and
+                        // one v_pk_fma_f32 per pair (bv holds 0.2 * bias here); fp8 mode is not held to the oracle's rounding order
                         const f32x4 th = half4_to_float(t_in[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+                        f32x4 rr;
+                        if (EPI == EPI_RDB5_RRDB) rr = half4_to_float(r_in[EPI == EPI_RDB5_RRDB ? np & 1 : 0][EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                        float y[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), th[i]);
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            f32x2 a, c, r;
+                            a[0] = acc[ct][np][4 * g + 2 * h2]; a[1] = acc[ct][np][4 * g + 2 * h2 + 1];
+                            c[0] = th[2 * h2] + bv[ct][4 * g + 2 * h2]; c[1] = th[2 * h2 + 1] + bv[ct][4 * g + 2 * h2 + 1];
+                            f32x2 w2 = __builtin_elementwise_fma(a, (f32x2){0.2f, 0.2f}, c);
                             if (EPI == EPI_RDB5_RRDB) {
-                                const f32x4 rr = half4_to_float(r_in[EPI == EPI_RDB5_RRDB ? np & 1 : 0][EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-                                v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), rr[i]);
+                                r[0] = rr[2 * h2]; r[1] = rr[2 * h2 + 1];
+                                w2 = __builtin_elementwise_fma(w2, (f32x2){0.2f, 0.2f}, r);
                             }
+                            v[2 * h2] = w2[0]; v[2 * h2 + 1] = w2[1];
+                            const f32x2 s2 = w2 * oscale;
+                            y[2 * h2] = __builtin_amdgcn_fmed3f(s2[0], -448.0f, 448.0f);
+                            y[2 * h2 + 1] = __builtin_amdgcn_fmed3f(s2[1], -448.0f, 448.0f);
                         }
                         f16x4 hv;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
                         hpk[g] = __builtin_bit_cast(u32x2, hv);
-                        // the conv operand is the e4m3 image of what the trunk actually carries (the fp16 value)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = (float)hv[i];
+                        int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
+                        q8[g] = (uint32_t)w;
+                        continue;
                     }
                     q8[g] = to_e4m3x4(v, oscale);
                 }
