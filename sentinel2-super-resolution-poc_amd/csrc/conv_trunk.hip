@@ -266,6 +266,27 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 
     int kglob = 0;   // TRACE only
 
+    // conv5: the trunk-lo operands of the patch's own pixels are requested at the START of the patch's last stage, straight
+    // into AGPRs, and arrive under its MFMAs instead of stalling the epilogue for an HBM round trip
+    u32x2 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
+    auto prefetch_lo = [&](int it) __attribute__((always_inline)) {
+        const int tile = it * nwg + slot_in_round;
+        const int n = tile / tpi;
+        const int trem = tile - n * tpi;
+        const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+        const size_t ln = (size_t)n * 4 * oblk;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const size_t opix = (size_t)(ty * G::TH + wave * NP + np + 1) * p.Wp + (tx * G::TW + pcol + 1);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
+                        asm_load8(p.xh_in + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix * 32 + (g & 1) * 16 + hh * 8);   // xh_in: the trunk lo coming in
+        }
+    };
+
     // One stage.  FIRST: first stage of a patch (accumulators start from C = 0; the barrier inside it may also
     // leave the previous patch's epilogue stores in flight).  CAP >= 0: capture x block CAP for the trunk epilogue.
     auto stage = [&](auto first_tag, auto cap_tag, bool first_patch) __attribute__((always_inline)) {
@@ -364,30 +385,18 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensors, bytes
-        u32x2 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
         u32x2 rhi[EPI == EPI_RDB5_RRDB ? CT : 1][4], rlo[EPI == EPI_RDB5_RRDB ? CT : 1][4];   // RRDB skip as an fp16 pair
         const size_t sn = (size_t)n * p.xh_img;   // image offset inside the skip-hi tensor, bytes
-        auto load_lo = [&](int np) __attribute__((always_inline)) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
-                        asm_load8(p.xh_in + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8);   // xh_in: the trunk lo coming in
-        };
         if (kTrunk) {
+            // the prefetched trunk lo: only the last stage's DMA instructions are younger
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PW) : "memory");
 #pragma unroll
-            for (int np = 0; np < NP; ++np) load_lo(np);
-            if (EPI == EPI_RDB5) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int np = 0; np < NP; ++np)
 #pragma unroll
-                for (int np = 0; np < NP; ++np)
+                for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) asm_land(lo_old[ct][np][g]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                    for (int g = 0; g < 4; ++g) asm_land(lo_old[ct][np][g]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
@@ -407,10 +416,6 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     for (int g = 0; g < 4; ++g) {
                         asm_land(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
                         asm_land(rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-                        if (np == 0) {
-#pragma unroll
-                            for (int q = 0; q < NP; ++q) asm_land(lo_old[ct][q][g]);
-                        }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -492,7 +497,9 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false);
             stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false);
             stage(integral_constant<bool, false>{}, integral_constant<int, 3>{}, false);
-            for (int st = 4; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+            for (int st = 4; st < NS - 1; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+            prefetch_lo(it);                                      // NS >= 5 (host): the last stage is peeled, the loads ride on it
+            stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
         } else {
             stage(integral_constant<bool, true>{}, integral_constant<int, -1>{}, first_patch);
             for (int st = 1; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
@@ -534,7 +541,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     }
     // operand shapes the kernel's indexing assumes (a violation would read or write outside the tensors)
     if (p.nstage < 1 || p.nstage > 12 || p.sHp != p.Hp || p.sWp != p.Wp || p.Hp < p.H + 2 || p.Wp < p.W + 2) return hipErrorInvalidValue;
-    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 4 || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 5 || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
         return hipErrorInvalidValue;   // T = trunk lo out, xh_in = trunk lo in, (xh_skip, lo_skip) = the RRDB's input as an fp16 pair
     if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;   // slabs of edge patches stay inside the plane
     if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash) return hipErrorInvalidValue;
@@ -1032,9 +1039,12 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     const int sbx = 127 - p.x_exp, sbg = 127 - p.g_exp;
     for (int it = 0; it < my_tiles; ++it) {
         step(integral_constant<bool, true>{}, it == 0, sbx);      // planes 0, 1 = x
-        for (int st = 1; st < NSTEP; ++st) {
-            if (kTrunk && st == NSTEP - 1) prefetch_residuals(it);   // conv5: NSTEP == 3 (host)
+        if (kTrunk) {                                             // conv5: NSTEP >= 2 (host); the last pair-step is peeled
+            for (int st = 1; st < NSTEP - 1; ++st) step(integral_constant<bool, false>{}, false, sbg);
+            prefetch_residuals(it);
             step(integral_constant<bool, false>{}, false, sbg);
+        } else {
+            for (int st = 1; st < NSTEP; ++st) step(integral_constant<bool, false>{}, false, sbg);
         }
         epilogue(it);
     }
