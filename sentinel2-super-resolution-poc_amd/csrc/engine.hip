@@ -1322,6 +1322,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     p.src = D0; p.src_img = 12 * blk; p.nstage = cin / 16;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
     p.T = T; p.R = Rr; p.F = Rr; p.trash = h->d_trash;
+    p.xh_in = T;   // conv_trunk_f16: trunk lo coming in (here read and written in place: timing only)
     p.dbg = getenv("S2SR_DBG") ? atoi(getenv("S2SR_DBG")) : 0;
     int epi;
     if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }
