@@ -36,6 +36,11 @@
 
 #include "s2sr_internal.h"
 
+#ifndef S2SR_L2PF
+#define S2SR_L2PF 0        // conv_trunk_f16: stages an L2 prefetch runs ahead of the LDS-DMA cursor.  Measured (tools/ab_macro.sh,
+                           // profiles/r02_trunk_anatomy.txt): 1 -> -5 %, 2 -> -15 % on conv1-4: the LDS-DMA path is throughput-, not
+                           // latency-bound, extra requests cost.  Kept as a switch, off.
+#endif
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
@@ -64,12 +69,19 @@ struct TG {
     static constexpr int STAGE_BYTES = NSTI * 1024;
     static constexpr int RING_BYTES = R * STAGE_BYTES;
     static constexpr int BIAS_OFF = RING_BYTES;
-    static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
+    static constexpr int PF_OFF = BIAS_OFF + CT * 128;         // 256-B landing pad of the L2 prefetch
+    static constexpr int LDS_BYTES = PF_OFF + 256;
     static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per stage
-    static constexpr int NW = PW * (R - 2);                    // DMA instructions that may stay in flight at a barrier
+    // L2 prefetch of a later stage's slab: one 4-byte LDS-DMA lane per 128-B line (9 lines per slab row) into a dummy LDS
+    // word -- no register destination, counted in vmcnt like every other vector-memory operation
+    static constexpr int PFL = S2SR_L2PF > 0 ? SH * 9 : 0;     // lines per slab plane
+    static constexpr int PFW = (PFL + 64 * WAVES - 1) / (64 * WAVES);   // prefetch instructions per wave and stage
+    static constexpr int PV = PW + PFW;                        // vector-memory instructions per wave and stage
+    static constexpr int NW = PV * (R - 2);                    // ... that may stay in flight at a barrier
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
     static_assert(PW <= T - 3, "DMA slots must fit in front of the barrier step");
+    static_assert(S2SR_L2PF <= R - 1 || S2SR_L2PF == 0 || true, "");
 };
 
 // LDS-DMA, 16 B per lane (conv3x3.hip glds16).  FORCE_UNIFORM: the stamped diagnostic build's divergent stamp
@@ -205,7 +217,38 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             else st_i = NS - 1;                                   // clamp: re-load the last stage (into a free slot)
         }
     };
+    // ---- L2 prefetch cursor: S2SR_L2PF stages further ahead than the DMA cursor.  The DMA throughput of a CU is
+    // (bytes in flight) / latency and the bytes in flight are capped by the LDS ring; pulling a stage's lines into L2 early
+    // shortens the latency its LDS-DMA sees later.
+    int it_p = 0, st_p = 0;
+    const char* pbase_p = nullptr;
+    const char* sb_p = nullptr;
+    auto pf_next = [&]() __attribute__((always_inline)) {
+        if (st_p == 0) {
+            const int tile = it_p * nwg + slot_in_round;
+            const int n = tile / tpi;
+            const int trem = tile - n * tpi;
+            const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
+            pbase_p = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
+        }
+        sb_p = pbase_p + (size_t)st_p * sblk;
+        if (++st_p == NS) {
+            if (it_p + 1 < my_tiles) { st_p = 0; ++it_p; }
+            else st_p = NS - 1;
+        }
+    };
+    uint32_t pfoff[G::PFW > 0 ? G::PFW : 1];
+#pragma unroll
+    for (int k = 0; k < G::PFW; ++k) {
+        int l = (wave + k * 4) * 64 + lane;                       // line of the slab plane
+        if (l >= G::PFL) l = G::PFL - 1;
+        pfoff[k] = (uint32_t)((l / 9) * p.sWp * 32 + (l % 9) * 128);
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    auto pf_piece = [&](int k) __attribute__((always_inline)) {
+        uint32_t m = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)G::PF_OFF);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(pfoff[k]), "s"(sb_p), "s"(m) : "memory");
+    };
     auto dma_piece = [&](int sl, uint32_t slot_off) __attribute__((always_inline)) {
         int j = wave + sl * 4;
         if (j > G::NSTI - 1) j = G::NSTI - 1;
@@ -245,12 +288,26 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
     f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
 
-    // ---- prologue: R-1 stages in flight, then the first fragments of stage 0
+    // ---- prologue: R-1 stages in flight (+ the L2 prefetch of the stages behind them), then the first fragments of stage 0
+    if (G::PFW > 0) {
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) pf_next();                // the stages the DMA below fetches itself
+    }
 #pragma unroll
     for (int r = 0; r < R - 1; ++r) {
         cursor_next();
 #pragma unroll
         for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, (uint32_t)(r * G::STAGE_BYTES));
+        // keep every wave's instruction count per "stage" at PV: the first S2SR_L2PF prefetches ride here
+        if (G::PFW > 0) {
+            if (r < S2SR_L2PF) pf_next();
+#pragma unroll
+            for (int k = 0; k < G::PFW; ++k) pf_piece(k);
+        }
+    }
+    if (G::PFW > 0) {
+#pragma unroll
+        for (int r = R - 1; r < S2SR_L2PF; ++r) pf_next();        // (only when the prefetch runs further ahead than R-1 prologue rounds)
     }
     uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
     wait_release_barrier<G::NW>();                                // stage 0 has landed (and the bias is visible)
@@ -297,6 +354,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         const char* sb = smem + cur_off;
         const char* sn = smem + next_off;
         cursor_next();                                            // the stage R-1 ahead: its DMA rides on this stage
+        if (G::PFW > 0) pf_next();                                // and S2SR_L2PF stages beyond it: L2 prefetch
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
@@ -336,6 +394,9 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
                 if ((sl * (G::T - 3)) / G::PW == t) dma_piece(sl, dma_off);
+#pragma unroll
+            for (int k = 0; k < G::PFW; ++k)
+                if (((2 * k + 1) * (G::T - 3)) / (2 * G::PFW) == t) pf_piece(k);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int np = s - dy;
@@ -389,7 +450,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         const size_t sn = (size_t)n * p.xh_img;   // image offset inside the skip-hi tensor, bytes
         if (kTrunk) {
             // the prefetched trunk lo: only the last stage's DMA instructions are younger
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PV) : "memory");
 #pragma unroll
             for (int np = 0; np < NP; ++np)
 #pragma unroll
@@ -587,34 +648,41 @@ __device__ __forceinline__ void mfma8_first_bias(f32x16& acc, const v8i& a, cons
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %5, %3, %4 op_sel_hi:[0,0,0]" : "=&a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb), "a"(bias));
 }
 
-template <int CT_, int NP_, int RS_>
+template <int CT_, int NP_, int RS_, int WV_ = 4, int NPL_ = 0>
 struct TG8 {
-    static constexpr int CT = CT_, NP = NP_, RS = RS_, WAVES = 4;
+    static constexpr int CT = CT_, NP = NP_, RS = RS_, WAVES = WV_;
+    // NPL > 0: ALL of the conv's weight planes (up to NPL, 9*CT KiB each) are loaded into LDS once per workgroup and stay:
+    // no weight DMA in the loop (+1 % on conv1-3, see launch_conv_trunk_f8).
+    static constexpr int NPL = NPL_;
+    static constexpr bool WRES = NPL_ > 0;
     static constexpr int TH = WAVES * NP, TW = 32, SW = TW + 2, SH = TH + 2, SPX = SH * SW;
     static constexpr int ROWB = SW * 32;
     static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
     static constexpr int PI = PLANE / 1024;                     // slab DMA pieces per plane
     static constexpr int WI = 9 * CT;                           // weight DMA pieces per plane
-    static constexpr int PWS = 2 * (PI / WAVES);                // slab DMA instructions per wave and pair-step
-    static constexpr int PWW = (2 * WI + WAVES - 1) / WAVES;    // weight DMA instructions per wave and pair-step
+    static constexpr bool CTMAP = (PI % WAVES == 0);            // piece -> plane mapping is a compile-time property of the slot
+    static constexpr int PWS = CTMAP ? 2 * (PI / WAVES) : (2 * PI + WAVES - 1) / WAVES;   // slab DMA instructions per wave and pair-step
+    static constexpr int PWW = WRES ? 0 : (2 * WI + WAVES - 1) / WAVES;    // weight DMA instructions per wave and pair-step
     static constexpr int ND = PWS + PWW;
     static constexpr int WBYTES = 2 * WI * 1024;                // one weight slot (two planes)
     static constexpr int WOFF = RS * PLANE;
-    static constexpr int BIAS_OFF = WOFF + 2 * WBYTES;
+    static constexpr int BIAS_OFF = WOFF + (WRES ? NPL * WI * 1024 : 2 * WBYTES);
     static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
     static constexpr int T = 3 * (NP + 2);
     static constexpr int AHEAD = RS / 2 - 1;                    // pair-steps the slab DMA runs ahead
     static constexpr int NW = (AHEAD - 1) * PWS;                // DMA instructions that may stay in flight at a barrier
     static_assert(RS % 2 == 0 && RS >= 4, "slab ring holds whole pairs");
-    static_assert(PI % WAVES == 0, "each plane's slab pieces split evenly over the waves (piece -> plane is then compile-time)");
-    static constexpr int PWP = PI / WAVES;                       // slab DMA instructions per wave and PLANE
+    static_assert(CTMAP || (2 * PI) % WAVES == 0, "the pair's slab pieces split evenly over the waves");
+    static constexpr int PWP = CTMAP ? PI / WAVES : PWS;         // loffS entries: per plane (compile-time map) or per slot
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
 };
 
-template <int CT, int NP, int RS, int EPI>
-__global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
-    using G = TG8<CT, NP, RS>;
+// WV = 4: one wave per SIMD (512 registers).  WV = 8 (conv1-4 form): two waves per SIMD with 256 registers each -- the fp8
+// form is bound by ONE wave's issue port (PMC: 47 % of wave cycles issuing, 35 % MFMA busy), which a second wave doubles.
+template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0>
+__global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParams p) {
+    using G = TG8<CT, NP, RS, WV, NPL>;
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert((EPI == EPI_LRELU && CT == 1) || (kTrunk && CT == 2), "conv1-4: 32 couts; conv5: 64 couts");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -645,7 +713,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     uint32_t loffS[G::PWP];
 #pragma unroll
     for (int sl = 0; sl < G::PWP; ++sl) {
-        const int jj = wave + sl * 4;
+        int jj = wave + sl * WV;
+        if (!G::CTMAP && jj >= G::PI) jj -= G::PI;               // run-time map: slot sl of this wave is piece jj of plane (wave + sl*WV) / PI
         const int i = jj * 64 + lane;
         int q = i >> 1;
         if (q >= G::SPX) q = 0;
@@ -703,16 +772,24 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         mW = lds0 + G::WOFF + wslot * G::WBYTES + (uint32_t)wave * 1024;
     };
     auto dma_slab = [&](int sl) __attribute__((always_inline)) {        // sl is a compile-time constant at every call
-        const bool second = sl >= G::PWP;
-        const int k = second ? sl - G::PWP : sl;
-        glds16<false>(second ? sB : sA, (second && ph_slab) ? 0u : loffS[k], (second ? mB : mA) + (uint32_t)k * 4096);
+        if (G::CTMAP) {
+            const bool second = sl >= G::PWP;
+            const int k = second ? sl - G::PWP : sl;
+            glds16<false>(second ? sB : sA, (second && ph_slab) ? 0u : loffS[k], (second ? mB : mA) + (uint32_t)k * (WV * 1024));
+        } else {
+            const int i = wave + sl * WV;                                // wave-uniform
+            const bool second = i >= G::PI;
+            const int jj = second ? i - G::PI : i;
+            glds16<false>(second ? sB : sA, (second && ph_slab) ? 0u : loffS[sl],
+                          (second ? mB : mA) + (uint32_t)(jj - wave) * 1024);
+        }
     };
     auto dma_wts = [&](int sl) __attribute__((always_inline)) {
-        // piece i = wave + 4*sl of the pair's 2*WI KiB; past the end (last sl only): the last piece again
-        const bool over = (sl * 4 + 3 > 2 * G::WI - 1) && (wave + sl * 4 > 2 * G::WI - 1);
-        const uint32_t back = over ? (uint32_t)(wave + sl * 4 - (2 * G::WI - 1)) * 1024 : 0u;
-        const bool zero = ph_wts && (sl * 4 >= G::WI || (sl * 4 + 3 >= G::WI && wave + sl * 4 >= G::WI));   // piece of the phantom's zero block
-        glds16<false>(wS, zero ? (uint32_t)(G::WI * 1024) : lane16w + (uint32_t)sl * 4096 - back, mW + (uint32_t)sl * 4096 - back);
+        // piece i = wave + WV*sl of the pair's 2*WI KiB; past the end (last sl only): the last piece again
+        const bool over = (sl * WV + WV - 1 > 2 * G::WI - 1) && (wave + sl * WV > 2 * G::WI - 1);
+        const uint32_t back = over ? (uint32_t)(wave + sl * WV - (2 * G::WI - 1)) * 1024 : 0u;
+        const bool zero = ph_wts && (sl * WV >= G::WI || (sl * WV + WV - 1 >= G::WI && wave + sl * WV >= G::WI));   // piece of the phantom's zero block
+        glds16<false>(wS, zero ? (uint32_t)(G::WI * 1024) : lane16w + (uint32_t)sl * (WV * 1024) - back, mW + (uint32_t)sl * (WV * 1024) - back);
     };
 
     // ---- fragment addresses: per-lane base + immediate.  b0 / b1 = logical 16-B halves 0 / 1 of pixel (row, pcol + dx)
@@ -756,18 +833,29 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     // ---- prologue
     uint32_t cur_slot = 0;        // slab ring slot of the current pair's first plane
     uint32_t cur_w = 0;           // weight slot of the current pair
+    uint32_t cur_st = 0;          // pair-step inside the patch
     {
         slab_next();              // slabs of pair-step 0
         dma_targets(0, 0);
 #pragma unroll
         for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl);
-        wts_next();               // weights of pair-steps 0 and 1
+        if (G::WRES) {
+            // every weight plane of this conv, once: piece i = wave + WV*k of nstage * WI KiB, straight copy of the packed block
+            const int npieces = p.nstage * G::WI;
+            for (int k = 0; k * WV < npieces; ++k) {
+                int i = wave + k * WV;
+                if (i > npieces - 1) i = npieces - 1;
+                glds16<false>((const char*)p.wpack, (uint32_t)lane * 16 + (uint32_t)i * 1024, lds0 + G::WOFF + (uint32_t)i * 1024);
+            }
+        } else {
+            wts_next();               // weights of pair-steps 0 and 1
 #pragma unroll
-        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
-        wts_next();
-        dma_targets(0, 1);
+            for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
+            wts_next();
+            dma_targets(0, 1);
 #pragma unroll
-        for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
+            for (int sl = 0; sl < G::PWW; ++sl) dma_wts(sl);
+        }
 #pragma unroll
         for (int a = 1; a < G::AHEAD; ++a) {
             slab_next();
@@ -824,7 +912,11 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         uint32_t dma_slot = cur_slot + 2 * G::AHEAD;
         while (dma_slot >= (uint32_t)RS) dma_slot -= RS;
         const uint32_t ls = lane_slab_of(cur_slot), lsn = lane_slab_of(next_slot);
-        const uint32_t wo = cur_w * G::WBYTES, won = (cur_w ^ 1) * G::WBYTES;
+        // weight block of this pair-step and of the next one: ring slot, or (resident) the pair's place in the conv's block
+        uint32_t nxt_st = cur_st + 1;
+        if (nxt_st == (uint32_t)NSTEP) nxt_st = 0;
+        const uint32_t wo = G::WRES ? cur_st * (uint32_t)G::WBYTES : cur_w * G::WBYTES;
+        const uint32_t won = G::WRES ? nxt_st * (uint32_t)G::WBYTES : (cur_w ^ 1) * G::WBYTES;
         slab_next();
         dma_targets(dma_slot, cur_w);
 #pragma unroll
@@ -838,7 +930,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
                 constexpr int NEPI = (G::AHEAD >= 2) ? G::NW + CT * NP : 0;      // conv1-4 form: CT*NP plane stores per wave
                 if (FIRST && !first_patch && G::AHEAD >= 2) wait_release_barrier<NEPI>();
                 else wait_release_barrier<G::NW>();
-                wts_next();                                   // two pair-steps ahead: into the weight slot this barrier released
+                if (!G::WRES) wts_next();                     // two pair-steps ahead: into the weight slot this barrier released
             }
             {
                 const int u = t + 3;
@@ -880,6 +972,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
         }
         cur_slot = next_slot;
         cur_w ^= 1;
+        cur_st = nxt_st;
     };
 
     // e4m3 x4 of four floats scaled by 2^e, clamped to the finite range (v_cvt_pk_fp8_f32 turns overflow into NaN)
@@ -1051,12 +1144,13 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f8(const ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int CT, int NP, int RS, int EPI>
+template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0>
 hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
-    using G = TG8<CT, NP, RS>;
+    using G = TG8<CT, NP, RS, WV, NPL>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS rings do not fit");
     static_assert(G::NW >= 0 && G::NW < 64, "vmcnt field is 6 bits");
-    auto kern = conv_trunk_f8<CT, NP, RS, EPI>;
+    auto kern = conv_trunk_f8<CT, NP, RS, EPI, WV, NPL>;
+    if (NPL > 0 && p.nstage > NPL) return hipErrorInvalidValue;   // resident weights: the conv's planes must fit the LDS block
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -1090,7 +1184,7 @@ hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
     const int ntiles = q.tilesX * q.tilesY * p.N;
     int grid = ncu & ~7;
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WV * 64), G::LDS_BYTES, st, q);
     return hipGetLastError();
 }
 
@@ -1157,7 +1251,17 @@ void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int
 }
 
 hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_t st) {
-    if (ct == 1 && epi == EPI_LRELU) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
+    if (ct == 1 && epi == EPI_LRELU) {
+        static const bool w8 = [] { const char* e = getenv("S2SR_FP8_W8"); return e && atoi(e) != 0; }();
+        // S2SR_FP8_WSTREAM: 0 (default) conv1-3 keep their weights resident in LDS (<= 4 planes incl. a phantom, next to the 6-slot
+        // slab ring), conv4 streams them (6 planes would cost two slab slots); 1 all stream; 2 all resident (conv4 on a 4-slot ring).
+        // Measured on one box, conv1-4 per 5 steps: 108.7 / 109.8 / 111.9 ms -- +1 %, nothing like the -18 % a "no weight DMA"
+        // diagnostic suggested (that one read zeros as weights, and an MFMA fed zeros draws less power: the chip clocked higher).
+        static const int stream_w = [] { const char* e = getenv("S2SR_FP8_WSTREAM"); return e ? atoi(e) : 0; }();
+        if (w8) return launch_trunk8_t<1, 2, 6, EPI_LRELU, 8>(p, st);
+        if (stream_w == 1 || (stream_w == 0 && p.nstage > 4)) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
+        return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4>(p, st) : launch_trunk8_t<1, 4, 4, EPI_LRELU, 4, 6>(p, st);
+    }
     if (ct == 2 && epi == EPI_RDB5) return launch_trunk8_t<2, 4, 4, EPI_RDB5>(p, st);
     if (ct == 2 && epi == EPI_RDB5_RRDB) return launch_trunk8_t<2, 4, 4, EPI_RDB5_RRDB>(p, st);
     return hipErrorNotSupported;
