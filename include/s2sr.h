@@ -103,7 +103,8 @@ const char* s2sr_last_error(const s2sr_handle* h);   /* h may be NULL: last crea
 int  s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats);
 size_t s2sr_expected_blob_floats(int32_t num_block);
 /* same blob, DEVICE-resident (e.g. the receive buffer of the RCCL weight broadcast); `stream`
- * is the stream the blob was produced on (a hipStream_t; NULL = default stream).  Returns when loaded. */
+ * is the stream the blob was produced on (a hipStream_t; NULL = default stream).  Returns when loaded.  The RDB convs are
+ * repacked on the device; only the six head/tail convs' weights (0.9 MB) pass through host memory. */
 int  s2sr_load_weights_dev(s2sr_handle* h, const void* d_blob, size_t n_floats, void* stream);
 
 /* pure host function = the index math of _tile_process (cnn_super_resolution.py:244-278) */

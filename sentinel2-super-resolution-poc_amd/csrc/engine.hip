@@ -31,6 +31,7 @@ struct ConvW {
     // to even, seg_len = real planes) + per-output-channel E8M0 scale bytes
     bool f8trunk = false;
     int32_t* d_wscale = nullptr;
+    bool pooled = false;                // d_wpack / d_wscale point into the handle's pools
 };
 
 // kernel families for the HIP-event statistics
@@ -95,6 +96,11 @@ struct s2sr_handle {
     std::mutex mu;
     std::string err;
     std::vector<ConvW> convs;
+    // the packed weights of the 345 RDB convs, their fp8 scales and every conv's bias live in three pooled allocations
+    // (ConvW pointers point into them); only the six head/tail convs own separate buffers (pooled == false)
+    char* pool_w = nullptr;
+    int32_t* pool_s = nullptr;
+    float* pool_b = nullptr;
     bool has_weights = false;
     char* d_trash = nullptr;      // parking area for out-of-image epilogue stores
     Workspace ws;
@@ -154,6 +160,19 @@ std::vector<ConvSpec> conv_specs(int num_block) {
     v.push_back({64, 64});   // conv_hr
     v.push_back({64, 3});    // conv_last
     return v;
+}
+
+void free_weights(s2sr_handle* h) {
+    for (ConvW& c : h->convs) {
+        if (!c.pooled && c.d_wpack) hipFree(c.d_wpack);
+        for (int k = 0; k < 2; ++k)
+            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
+    }
+    if (h->pool_w) hipFree(h->pool_w);
+    if (h->pool_s) hipFree(h->pool_s);
+    if (h->pool_b) hipFree(h->pool_b);
+    h->pool_w = nullptr; h->pool_s = nullptr; h->pool_b = nullptr;
+    h->convs.clear();
 }
 
 void drop_graphs(s2sr_handle* h) {   // buffers or weights moved: every captured pointer is stale
@@ -631,13 +650,7 @@ void s2sr_destroy(s2sr_handle* h) {
     hipSetDevice(h->cfg.device);
     hipDeviceSynchronize();
     drop_graphs(h);
-    for (ConvW& c : h->convs) {
-        if (c.d_wpack) hipFree(c.d_wpack);
-        if (c.d_bias) hipFree(c.d_bias);
-        if (c.d_wscale) hipFree(c.d_wscale);
-        for (int k = 0; k < 2; ++k)
-            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
-    }
+    free_weights(h);
     if (h->ws.base) hipFree(h->ws.base);
     if (h->d_trash) hipFree(h->d_trash);
     for (int i = 0; i < 6; ++i)
@@ -650,10 +663,10 @@ void s2sr_destroy(s2sr_handle* h) {
     delete h;
 }
 
-int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
-    if (!h || !blob) return S2SR_E_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIPCHK(h, hipSetDevice(h->cfg.device));
+// Weights in, by either door.  `d_blob` is the fp32 blob ON THE DEVICE (the host entry uploads it first): the 345 RDB convs
+// are repacked by device kernels straight from it (pack.hip), every bias is gathered on the device; only the six head/tail
+// convs (0.9 MB of the 67 MB) come back to the host, because their split-operand / sub-pixel packers are host code.
+static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_floats, hipStream_t st) {
     const std::vector<ConvSpec> specs = conv_specs(h->cfg.num_block);
     const size_t want = s2sr_expected_blob_floats(h->cfg.num_block);
     if (n_floats != want) {
@@ -663,22 +676,43 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     }
     HIPCHK(h, hipDeviceSynchronize());
     drop_graphs(h);
-    for (ConvW& c : h->convs) {
-        if (c.d_wpack) hipFree(c.d_wpack);
-        if (c.d_bias) hipFree(c.d_bias);
-        if (c.d_wscale) hipFree(c.d_wscale);
-        for (int k = 0; k < 2; ++k)
-            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
-    }
-    h->convs.clear();
+    free_weights(h);
     h->has_weights = false;
-    const float* pw = blob;
-    std::vector<char> tmp;
     const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
     const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || (fp8 && h->fp8_hp_tail);
     const size_t nconv = specs.size();
-    size_t idx = 0;
-    for (const ConvSpec& s : specs) {
+    // ---- plan: blob offsets, pooled sizes
+    std::vector<uint64_t> woff(nconv), boff(nconv), poff(nconv, 0);
+    std::vector<int32_t> couts(nconv);
+    size_t off = 0, pool_bytes = 0;
+    for (size_t i = 0; i < nconv; ++i) {
+        woff[i] = off; off += (size_t)specs[i].cin * specs[i].cout * 9;
+        boff[i] = off; off += specs[i].cout;
+        couts[i] = specs[i].cout;
+        const bool trunk = i >= 1 && i + 5 < nconv;
+        if (trunk) {
+            poff[i] = pool_bytes;
+            pool_bytes += align256(fp8 ? conv_wpack_bytes_f8(specs[i].cin, specs[i].cout) : conv_wpack_bytes(specs[i].cin, specs[i].cout));
+        }
+    }
+    HIPCHK(h, hipMalloc((void**)&h->pool_w, pool_bytes ? pool_bytes : 256));
+    HIPCHK(h, hipMalloc((void**)&h->pool_b, nconv * 64 * sizeof(float)));
+    if (fp8) HIPCHK(h, hipMalloc((void**)&h->pool_s, nconv * 64 * sizeof(int32_t)));
+    {   // biases: one gather kernel
+        uint64_t* d_off = nullptr;
+        int32_t* d_cout = nullptr;
+        HIPCHK(h, hipMalloc((void**)&d_off, nconv * 8));
+        HIPCHK(h, hipMalloc((void**)&d_cout, nconv * 4));
+        HIPCHK(h, hipMemcpyAsync(d_off, boff.data(), nconv * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(d_cout, couts.data(), nconv * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(h, launch_gather_bias(d_blob, d_off, d_cout, (int)nconv, h->pool_b, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        hipFree(d_off); hipFree(d_cout);
+    }
+    std::vector<char> tmp;
+    std::vector<float> hw;
+    for (size_t idx = 0; idx < nconv; ++idx) {
+        const ConvSpec& s = specs[idx];
         ConvW cw;
         const int nb = (s.cin + 15) / 16;
         // split-operand convs: the six outside the RRDB trunk (conv_first, conv_body, up1, up2, hr, last)
@@ -693,72 +727,77 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
         cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold || f8) ? 0x2 : 0x0;
         cw.f8 = f8;
-        const bool f8trunk = fp8 && idx >= 1 && idx + 5 < nconv;   // the 345 RDB convs
-        const size_t wb = f8trunk ? conv_wpack_bytes_f8(s.cin, s.cout) : conv_wpack_bytes_seg(s.cin, s.cout, nseg);
-        tmp.resize(wb);
-        if (f8trunk) {
-            int32_t wsc[64];
-            pack_conv_weights_f8(pw, s.cin, s.cout, tmp.data(), wsc);
-            cw.f8trunk = true;
-            cw.seg_len = (s.cin + 31) / 32;
-            cw.nstage = (cw.seg_len + 1) & ~1;
-            cw.seg_lo_mask = 0;
-            HIPCHK(h, hipMalloc((void**)&cw.d_wscale, sizeof wsc));
-            HIPCHK(h, hipMemcpy(cw.d_wscale, wsc, sizeof wsc, hipMemcpyHostToDevice));
-        } else if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
-        else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
         cw.fold = fold;
-        if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
-            const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
-            std::vector<char> ph(pb);
-            for (int k = 0; k < 2; ++k) {
-                pack_conv_weights_phase_f8hp(pw, s.cin, s.cout, k, ph.data());
-                HIPCHK(h, hipMalloc(&cw.d_wphase[k], pb));
-                HIPCHK(h, hipMemcpy(cw.d_wphase[k], ph.data(), pb, hipMemcpyHostToDevice));
+        cw.d_bias = h->pool_b + idx * 64;
+        const bool trunk = idx >= 1 && idx + 5 < nconv;     // the 345 RDB convs
+        if (trunk) {
+            cw.pooled = true;
+            cw.d_wpack = h->pool_w + poff[idx];
+            if (fp8) {
+                cw.f8trunk = true;
+                cw.seg_len = (s.cin + 31) / 32;
+                cw.nstage = (cw.seg_len + 1) & ~1;
+                cw.seg_lo_mask = 0;
+                cw.d_wscale = h->pool_s + idx * 64;
+                HIPCHK(h, launch_pack_trunk_f8(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, cw.d_wscale, st));
+            } else {
+                HIPCHK(h, launch_pack_trunk_f16(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, st));
             }
+        } else {
+            // head / tail conv: its weights come to the host for the split-operand / sub-pixel packers
+            hw.resize((size_t)s.cin * s.cout * 9);
+            HIPCHK(h, hipMemcpyAsync(hw.data(), d_blob + woff[idx], hw.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            const float* pw = hw.data();
+            const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
+            tmp.resize(wb);
+            if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
+            else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
+            if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
+                const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
+                std::vector<char> ph(pb);
+                for (int k = 0; k < 2; ++k) {
+                    pack_conv_weights_phase_f8hp(pw, s.cin, s.cout, k, ph.data());
+                    HIPCHK(h, hipMalloc(&cw.d_wphase[k], pb));
+                    HIPCHK(h, hipMemcpy(cw.d_wphase[k], ph.data(), pb, hipMemcpyHostToDevice));
+                }
+            }
+            HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
+            HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
         }
-        pw += (size_t)s.cin * s.cout * 9;
-        HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
-        HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
-        float bias[64] = {0};
-        memcpy(bias, pw, sizeof(float) * s.cout);
-        pw += s.cout;
-        HIPCHK(h, hipMalloc((void**)&cw.d_bias, sizeof bias));
-        HIPCHK(h, hipMemcpy(cw.d_bias, bias, sizeof bias, hipMemcpyHostToDevice));
         h->convs.push_back(cw);
-        ++idx;
     }
+    HIPCHK(h, hipStreamSynchronize(st));
     h->has_weights = true;
     return S2SR_OK;
 }
 
-// Device-resident blob (what an RCCL broadcast leaves on every rank): staged through pinned host memory
-// inside the library, because the repack to MFMA fragment order (pack_conv_weights*) is host code.  One
-// 67 MB copy per model load; the caller never touches host memory.
+int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
+    if (!h || !blob) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n_floats != s2sr_expected_blob_floats(h->cfg.num_block)) return load_weights_locked(h, nullptr, n_floats, h->stream);   // -> BADBLOB text
+    float* d_blob = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_blob, n_floats * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d_blob, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        hipFree(d_blob);
+        return fail(h, S2SR_E_HIP, std::string("upload of the weight blob failed: ") + hipGetErrorString(e));
+    }
+    const int rc = load_weights_locked(h, d_blob, n_floats, h->stream);
+    hipFree(d_blob);
+    return rc;
+}
+
+// Device-resident blob (what an RCCL broadcast leaves on every rank): repacked on the device; only the six head/tail convs'
+// weights (0.9 MB) visit the host.  `stream` = the stream the blob was produced on (NULL = default stream).
 int s2sr_load_weights_dev(s2sr_handle* h, const void* d_blob, size_t n_floats, void* stream) {
     if (!h || !d_blob) return S2SR_E_INVALID;
-    float* host = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        HIPCHK(h, hipSetDevice(h->cfg.device));
-        const size_t want = s2sr_expected_blob_floats(h->cfg.num_block);
-        if (n_floats != want) {
-            char b[160];
-            snprintf(b, sizeof b, "weight blob has %zu floats, a %d-block net needs %zu", n_floats, h->cfg.num_block, want);
-            return fail(h, S2SR_E_BADBLOB, b);
-        }
-        HIPCHK(h, hipHostMalloc((void**)&host, n_floats * sizeof(float), hipHostMallocDefault));
-        hipStream_t st = (hipStream_t)stream;
-        hipError_t e = hipMemcpyAsync(host, d_blob, n_floats * sizeof(float), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) {
-            hipHostFree(host);
-            return fail(h, S2SR_E_HIP, std::string("copy of the device blob failed: ") + hipGetErrorString(e));
-        }
-    }
-    const int rc = s2sr_load_weights(h, host, n_floats);
-    hipHostFree(host);
-    return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    return load_weights_locked(h, (const float*)d_blob, n_floats, h->stream);
 }
 
 int s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t scale, s2sr_window* out, int32_t cap,

@@ -140,6 +140,107 @@ hipError_t launch_xh_to_fp8(const char* xh, size_t xh_img, int N, int Hp, int Wp
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Device-side weight repack for the 345 RDB convs (the receive buffer of the RCCL weight broadcast goes straight into MFMA
+// fragment order: no host copy of the 67 MB blob).  Same layouts, same roundings as the host packers in conv3x3.hip /
+// conv_trunk.hip (pack_conv_weights nseg = 1, pack_conv_weights_f8), which stay for the six head/tail convs and the test hooks.
+// ------------------------------------------------------------------------------------------
+// fp16 trunk: out[stage][tap][ct][lane][8] = fp16(W[co = ct*32 + (lane&31)][ci = stage*16 + 8*(lane>>5) + j][tap])
+__global__ void pack_trunk_f16_kernel(const float* __restrict__ w, int cin, int cout, int ns, int CT, f16* __restrict__ out) {
+    const size_t total = (size_t)ns * 9 * CT * 64 * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+        size_t r = i >> 9;
+        const int ct = (int)(r % CT); r /= CT;
+        const int t = (int)(r % 9);
+        const int st = (int)(r / 9);
+        const int co = ct * 32 + (l & 31), ci = st * 16 + 8 * (l >> 5) + j;
+        out[i] = (co < cout && ci < cin) ? (f16)w[((size_t)co * cin + ci) * 9 + t] : (f16)0.f;
+    }
+}
+
+hipError_t launch_pack_trunk_f16(const float* d_w, int cin, int cout, void* d_out, hipStream_t st) {
+    const int ns = (cin + 15) / 16, CT = (cout + 31) / 32;
+    const size_t total = (size_t)ns * 9 * CT * 512;
+    hipLaunchKernelGGL(pack_trunk_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_w, cin, cout, ns, CT, (f16*)d_out);
+    return hipGetLastError();
+}
+
+// fp8 trunk, pass 1: per output channel the largest k with max|w_co| * 2^k < 448; wscale[co] = 127 - k (64 entries)
+__global__ void f8_scale_kernel(const float* __restrict__ w, int cin, int cout, int32_t* __restrict__ wscale) {
+    __shared__ float red[256];
+    const int co = blockIdx.x;
+    float m = 0.f;
+    if (co < cout)
+        for (int i = threadIdx.x; i < cin * 9; i += 256) m = fmaxf(m, fabsf(w[(size_t)co * cin * 9 + i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int k = 0;
+        m = red[0];
+        if (m > 0.f) {
+            int e;
+            const float f = frexpf(m, &e);            // m = f * 2^e, f in [0.5, 1); 448 = 0.875 * 2^9
+            k = (f < 0.875f ? 9 : 8) - e;
+        }
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        wscale[co] = 127 - k;
+    }
+}
+
+// pass 2: out[plane][tap][ct][16-B half][cout row][16] = e4m3(W * 2^k_co), phantom plane (odd plane counts) all zero
+__global__ void pack_trunk_f8_kernel(const float* __restrict__ w, int cin, int cout, int nreal, int npad, int CT,
+                                     const int32_t* __restrict__ wscale, uint8_t* __restrict__ out) {
+    const size_t total4 = (size_t)npad * 9 * CT * 256;          // groups of 4 bytes
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int j4 = (int)(i & 3), row = (int)((i >> 2) & 31), h16 = (int)((i >> 7) & 1);
+        size_t r = i >> 8;
+        const int ct = (int)(r % CT); r /= CT;
+        const int t = (int)(r % 9);
+        const int pl = (int)(r / 9);
+        const int co = ct * 32 + row;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pl < nreal && co < cout) {
+            const float sc = ldexpf(1.0f, 127 - wscale[co]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ci = 32 * pl + 16 * h16 + 4 * j4 + q;
+                if (ci < cin) v[q] = w[((size_t)co * cin + ci) * 9 + t] * sc;     // |v| < 448 by construction of k_co
+            }
+        }
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        ((uint32_t*)out)[i] = (uint32_t)pk;
+    }
+}
+
+hipError_t launch_pack_trunk_f8(const float* d_w, int cin, int cout, void* d_out, int32_t* d_wscale, hipStream_t st) {
+    const int nreal = (cin + 31) / 32, npad = (nreal + 1) & ~1, CT = (cout + 31) / 32;
+    hipLaunchKernelGGL(f8_scale_kernel, dim3(64), dim3(256), 0, st, d_w, cin, cout, d_wscale);
+    const size_t total4 = (size_t)npad * 9 * CT * 256;
+    hipLaunchKernelGGL(pack_trunk_f8_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, d_w, cin, cout, nreal, npad, CT, d_wscale,
+                       (uint8_t*)d_out);
+    return hipGetLastError();
+}
+
+// biases of all convs: blob offsets -> [nconv][64] fp32, zero padded
+__global__ void gather_bias_kernel(const float* __restrict__ blob, const uint64_t* __restrict__ off, const int32_t* __restrict__ cout,
+                                   int nconv, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nconv * 64) return;
+    const int c = i >> 6, k = i & 63;
+    out[i] = k < cout[c] ? blob[off[c] + k] : 0.f;
+}
+
+hipError_t launch_gather_bias(const float* d_blob, const uint64_t* d_off, const int32_t* d_cout, int nconv, float* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_bias_kernel, dim3((nconv * 64 + 255) / 256), dim3(256), 0, st, d_blob, d_off, d_cout, nconv, d_out);
+    return hipGetLastError();
+}
+
 __global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
                                       int T, int wh, int ww, uint8_t* __restrict__ tiles) {
     const size_t total = (size_t)T * wh * ww * 3;

@@ -101,6 +101,10 @@ hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_
 // w * 2^k_co, planes padded to an even count with a zero plane; wscale_out[co] = 127 - k_co
 size_t conv_wpack_bytes_f8(int cin, int cout);
 void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int32_t* wscale_out /*[64]*/);
+// device-side repack of the RDB convs' weights (pack.hip) and gather of all biases into [nconv][64]
+hipError_t launch_pack_trunk_f16(const float* d_w, int cin, int cout, void* d_out, hipStream_t st);
+hipError_t launch_pack_trunk_f8(const float* d_w, int cin, int cout, void* d_out, int32_t* d_wscale /*[64]*/, hipStream_t st);
+hipError_t launch_gather_bias(const float* d_blob, const uint64_t* d_off, const int32_t* d_cout, int nconv, float* d_out, hipStream_t st);
 hipError_t launch_xh_to_fp8(const char* xh, size_t xh_img, int N, int Hp, int Wp, int x_exp, char* out, size_t out_img, hipStream_t st);
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]

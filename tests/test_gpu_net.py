@@ -523,6 +523,16 @@ def test_rccl_world1_path():
         tiles = rng.integers(0, 256, size=(5, 24, 40, 3), dtype=np.uint8)
         assert np.array_equal(forward_batch_distributed(be, tiles), ref_e.forward_batch_u8(tiles))
         e.close()
+        # the device-side repack (fp16 and e4m3 trunk formats, bias gather) gives the bytes the host entry gives
+        import time
+        for prec in (native.PREC_F16, native.PREC_FP8):
+            e2 = native.Engine(num_block=nb, precision=prec)
+            t0 = time.perf_counter()
+            load_broadcast_weights(e2, synthetic_state_dict(nb, seed=0), nb, dev)
+            dt = time.perf_counter() - t0
+            assert np.array_equal(e2.forward_batch_u8(tiles), engine(nb, prec).forward_batch_u8(tiles)), prec
+            print(f"broadcast + device repack of a {nb}-block net (precision {prec}): {dt * 1e3:.1f} ms")
+            e2.close()
     finally:
         dist.destroy_process_group()
 
