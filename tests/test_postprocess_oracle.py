@@ -73,3 +73,20 @@ def test_pipelines_run():
     b = pp.farm_postprocess(img)
     assert a.shape == img.shape == b.shape and a.dtype == np.uint8
     assert not np.array_equal(a, b)
+
+
+def test_more_published_known_answers():
+    """Further 8-bit OpenCV values that follow from its documented formulas without any rounding ambiguity
+    (cvtColor docs: V = max, S = 255 (V - min) / V, H = 60 (G - B) / (V - min) [+120, +240] halved; addWeighted =
+    saturate_cast<uchar>(cvRound(.)), cvRound = round-half-to-even)."""
+    cols = np.array([[[0, 255, 255], [255, 0, 255], [128, 128, 128], [128, 0, 0], [0, 0, 128], [0, 128, 0], [255, 128, 0]]], np.uint8)
+    hsv = pp.rgb2hsv_u8(cols)[0].tolist()
+    assert hsv == [[90, 255, 255], [150, 255, 255], [0, 0, 128], [0, 255, 128], [120, 255, 128], [60, 255, 128], [15, 255, 255]]
+    assert np.array_equal(pp.hsv2rgb_u8(np.array([[[90, 255, 255], [150, 255, 255], [0, 0, 128]]], np.uint8)), cols[:, :3])
+    a = np.array([[[1, 3, 5], [255, 254, 0]]], np.uint8)
+    z = np.zeros_like(a)
+    assert pp.add_weighted_u8(a, 0.5, z, 0.0).tolist() == [[[0, 2, 2], [128, 127, 0]]]       # .5 ties go to the even neighbour
+    assert pp.add_weighted_u8(a, 2.0, a, -0.5).tolist() == [[[2, 4, 8], [255, 255, 0]]]      # 1.5->2, 4.5->4, 7.5->8; saturation
+    # the Lab L axis: L* = 116 (Y/Yn)^(1/3) - 16 scaled by 255/100; mid gray 128 -> Y = 0.2158 -> L* = 53.585 -> 136.6 -> 137
+    lab = pp.rgb2lab_u8(np.array([[[128, 128, 128], [255, 255, 255], [0, 0, 0]]], np.uint8))[0].tolist()
+    assert lab[1] == [255, 128, 128] and lab[2] == [0, 128, 128] and lab[0][1:] == [128, 128] and abs(lab[0][0] - 137) <= 1
