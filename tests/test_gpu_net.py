@@ -539,10 +539,10 @@ def test_rccl_world1_path():
 
 # S2SR_PREC_FP8 (BASELINE.json configs[4]): the 345 RDB convs on e4m3 operands.  e4m3 keeps 3 mantissa bits, so this mode
 # is NOT inside the north star's 1e-3; its tolerance is what it measures (MI355X, seeded x4plus-shaped weights):
-#   23 blocks: max-abs 4.8e-3 (rms 9.6e-4) on the golden at |y| max 2.7, 5.6e-3 (rms 6.1e-4) on a 256x256 tile;
-#   unscaled-body stress weights 1.8e-2;  6 blocks 1.2e-4;  u8 within 2 LSB (92-95 % of bytes identical)
-TOL_FP8_23 = 1.5e-2
-TOL_FP8_STRESS = 5e-2
+#   23 blocks: max-abs 3.5e-3 (rms 8.0e-4) on the golden at |y| max 2.7, 4.1e-3 (rms 6.2e-4) on a 256x256 tile;
+#   unscaled-body stress weights 1.0e-2;  6 blocks 1.1e-4;  u8 within 1 LSB (93-95 % of bytes identical)
+TOL_FP8_23 = 1e-2
+TOL_FP8_STRESS = 3e-2
 TOL_FP8_6 = 1e-3
 
 
