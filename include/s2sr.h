@@ -107,6 +107,14 @@ size_t s2sr_expected_blob_floats(int32_t num_block);
  * repacked on the device; only the six head/tail convs' weights (0.9 MB) pass through host memory. */
 int  s2sr_load_weights_dev(s2sr_handle* h, const void* d_blob, size_t n_floats, void* stream);
 
+/* S2SR_PREC_FP8 only: choose the two activation scales of the fp8 trunk from data.  Runs one forward of `tiles`
+ * ([B,th,tw,3] u8, host) with wide scales, takes the largest |x| of the trunk and |x_k| of the growth features over all
+ * RDBs, and sets the exponents so that headroom x those maxima stays below e4m3's 448 (headroom >= 1; 2 is a sane
+ * default: e4m3 is a floating format, so a wider scale costs precision only at its subnormal end).  The defaults (3 / 5) come from the synthetic calibration set, profiles/r02_fp8_scale_sweep.txt; a deployment
+ * with real checkpoints calls this once after s2sr_load_weights with a few representative tiles. */
+int  s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, float headroom,
+                        int32_t* x_exp, int32_t* g_exp);
+
 /* pure host function = the index math of _tile_process (cnn_super_resolution.py:244-278) */
 int  s2sr_plan_tiles(int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t scale,
                      s2sr_window* out, int32_t cap, int32_t* n);

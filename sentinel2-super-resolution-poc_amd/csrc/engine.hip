@@ -116,6 +116,7 @@ struct s2sr_handle {
     hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
     std::vector<hipEvent_t> group_done;
     // hipGraph replay of repeated groups
+    float* d_calib = nullptr;     // fp8 calibration: [0] max |x| of the trunk, [1] max |x_k| of the growth planes (device)
     bool fp8_hp_tail = false;     // S2SR_PREC_FP8: the six head / tail convs in plain fp16 (their ~2e-3 is below the trunk's e4m3
                                   // error) unless S2SR_FP8_TAIL=hp asks for the split-operand forms
     int fp8_x_exp = 3, fp8_g_exp = 5;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP); calibrated
@@ -399,6 +400,12 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
                     }
                     Scope sc(h, st, k < 5 ? F_RDB14 : F_RDB5, 2.0 * 9.0 * cw.cin * cw.cout * px, bytes);
                     HIPCHK(h, launch_conv_trunk_f8(p, cw.ct, epi, st));
+                }
+                if (h->d_calib) {   // s2sr_calibrate_fp8: ranges of this RDB's growth planes and of the trunk it produced
+                    HIPCHK(h, launch_absmax_e4m3(w.D8[cur] + 2 * w.blk1, (size_t)4 * w.blk1, ge, h->d_calib + 1, st));
+                    for (int i2 = 1; i2 < n; ++i2)
+                        HIPCHK(h, launch_absmax_e4m3(w.D8[cur] + (size_t)i2 * 6 * w.blk1 + 2 * w.blk1, (size_t)4 * w.blk1, ge, h->d_calib + 1, st));
+                    HIPCHK(h, launch_absmax_f16(w.Xh[(r + 1) % 3], (size_t)n * 4 * w.blk1 / 2, h->d_calib, st));
                 }
                 cur ^= 1;
             }
@@ -1267,6 +1274,52 @@ int s2sr_synchronize(s2sr_handle* h) {
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipDeviceSynchronize());
+    return S2SR_OK;
+}
+
+// Per-tensor-kind activation scales of the fp8 trunk from data: one forward of the calibration tiles with wide scales
+// (nothing clips), the largest |x| of the trunk and |x_k| of the growth planes over all RDBs, then the largest exponents
+// that keep `headroom` x those maxima below e4m3's 448.
+int s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, float headroom, int32_t* x_exp,
+                       int32_t* g_exp) {
+    if (!h || !tiles || B <= 0 || th <= 0 || tw <= 0 || !(headroom >= 1.0f)) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->cfg.precision != S2SR_PREC_FP8) return fail(h, S2SR_E_INVALID, "s2sr_calibrate_fp8 needs a handle created with S2SR_PREC_FP8");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t ib = (size_t)B * th * tw * 3, ob = ib * 16;
+    int rc = ensure_scratch(h, 0, ib);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(h, 1, ob))) return rc;
+    float* d_c = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_c, 2 * sizeof(float)));
+    HIPCHK(h, hipMemsetAsync(d_c, 0, 2 * sizeof(float), h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
+    const int old_x = h->fp8_x_exp, old_g = h->fp8_g_exp, old_prof = h->prof;
+    const bool old_graphs = h->graphs_on;
+    h->fp8_x_exp = 0; h->fp8_g_exp = 2;        // trunk up to 448, growth up to 112: measure without clipping
+    h->graphs_on = false; h->prof = 0;
+    h->d_calib = d_c;
+    rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0], nullptr, B, th, tw, (uint8_t*)h->d_scratch[1], nullptr);
+    h->d_calib = nullptr;
+    h->graphs_on = old_graphs; h->prof = old_prof;
+    float m[2] = {0.f, 0.f};
+    hipError_t e = hipMemcpyAsync(m, d_c, sizeof m, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_c);
+    if (rc || e != hipSuccess) {
+        h->fp8_x_exp = old_x; h->fp8_g_exp = old_g;
+        return rc ? rc : fail(h, S2SR_E_HIP, std::string("calibration read-back failed: ") + hipGetErrorString(e));
+    }
+    auto pick = [&](float mx, int fallback) {
+        if (!(mx > 0.f)) return fallback;
+        int k = (int)floorf(log2f(448.0f / (mx * headroom)));
+        return k > 12 ? 12 : (k < -8 ? -8 : k);
+    };
+    drop_graphs(h);                            // captured launches carry the old exponents
+    h->fp8_x_exp = pick(m[0], old_x);
+    h->fp8_g_exp = pick(m[1], old_g);
+    if (x_exp) *x_exp = h->fp8_x_exp;
+    if (g_exp) *g_exp = h->fp8_g_exp;
     return S2SR_OK;
 }
 

@@ -241,6 +241,39 @@ hipError_t launch_gather_bias(const float* d_blob, const uint64_t* d_off, const 
     return hipGetLastError();
 }
 
+// fp8 calibration: running max |v| of an fp16 blocked tensor / of an e4m3 plane tensor (whole padded extent: halos are
+// zero) into one float (bit pattern compared as unsigned: valid for non-negative floats)
+__global__ void absmax_f16_kernel(const f16* __restrict__ v, size_t n, float* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf((float)v[i]);
+        m = (a == a && a > m) ? a : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+__global__ void absmax_e4m3_kernel(const uint8_t* __restrict__ v, size_t n, float scale_inv, float* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = v[i] & 0x7f;
+        if (b == 0x7f) continue;                                  // NaN code (never stored: producers clamp)
+        const int e = b >> 3, mm = b & 7;
+        const float a = e == 0 ? (float)mm * 0.001953125f : ldexpf((float)(8 + mm), e - 10);
+        m = fmaxf(m, a);
+    }
+    m *= scale_inv;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out, __float_as_uint(m));
+}
+hipError_t launch_absmax_f16(const void* d, size_t n_halves, float* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_f16_kernel, dim3(1024), dim3(256), 0, st, (const f16*)d, n_halves, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_absmax_e4m3(const void* d, size_t n_bytes, int exp2, float* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(absmax_e4m3_kernel, dim3(1024), dim3(256), 0, st, (const uint8_t*)d, n_bytes, ldexpf(1.0f, -exp2), d_out);
+    return hipGetLastError();
+}
+
 __global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
                                       int T, int wh, int ww, uint8_t* __restrict__ tiles) {
     const size_t total = (size_t)T * wh * ww * 3;

@@ -105,6 +105,8 @@ void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int
 hipError_t launch_pack_trunk_f16(const float* d_w, int cin, int cout, void* d_out, hipStream_t st);
 hipError_t launch_pack_trunk_f8(const float* d_w, int cin, int cout, void* d_out, int32_t* d_wscale /*[64]*/, hipStream_t st);
 hipError_t launch_gather_bias(const float* d_blob, const uint64_t* d_off, const int32_t* d_cout, int nconv, float* d_out, hipStream_t st);
+hipError_t launch_absmax_f16(const void* d, size_t n_halves, float* d_out, hipStream_t st);               // fp8 calibration
+hipError_t launch_absmax_e4m3(const void* d, size_t n_bytes, int exp2, float* d_out, hipStream_t st);
 hipError_t launch_xh_to_fp8(const char* xh, size_t xh_img, int N, int Hp, int Wp, int x_exp, char* out, size_t out_img, hipStream_t st);
 size_t conv_wpack_bytes(int cin, int cout);
 // host-side repack: OIHW fp32 -> fp16 A-fragment order [stage][tap][ct][lane][8]

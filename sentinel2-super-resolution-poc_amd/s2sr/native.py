@@ -65,6 +65,8 @@ _PROTOS = {
     "s2sr_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "s2sr_expected_blob_floats": (C.c_size_t, [C.c_int32]),
     "s2sr_load_weights_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "s2sr_calibrate_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_int32),
+                                     C.POINTER(C.c_int32)]),
     "s2sr_plan_tiles": (C.c_int, [C.c_int32] * 5 + [C.POINTER(Window), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_forward_batch_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_forward_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -229,6 +231,15 @@ class Engine:
     def load_state_dict(self, sd):
         from .weights import flatten_state_dict
         self.load_blob(flatten_state_dict(sd, self.num_block))
+
+    def calibrate_fp8(self, tiles: np.ndarray, headroom: float = 2.0) -> tuple:
+        """PREC_FP8 engines: set the trunk's activation scales from representative tiles -> (x_exp, g_exp)."""
+        tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
+        B, h, w, c = tiles.shape
+        assert c == 3
+        xe, ge = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.s2sr_calibrate_fp8(self._h, _ptr(tiles), B, h, w, headroom, C.byref(xe), C.byref(ge)), "s2sr_calibrate_fp8")
+        return int(xe.value), int(ge.value)
 
     # -- forward ----------------------------------------------------------------------------
     def forward_batch_u8(self, tiles: np.ndarray) -> np.ndarray:

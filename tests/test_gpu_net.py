@@ -597,3 +597,35 @@ def test_fp8_mode_full_tile_and_batch_properties():
         img = np.random.default_rng(H).integers(0, 256, size=(H, W, 3), dtype=np.uint8)
         a, b = e.enhance_f32(img), hp.enhance_f32(img)
         assert a.shape == (4 * H, 4 * W, 3) and np.isfinite(a).all() and np.abs(a - b).max() <= TOL_FP8_23, (H, W)
+
+
+def test_fp8_calibration_sets_scales_from_data(golden_dir):
+    """s2sr_calibrate_fp8: activation scales of the fp8 trunk from the largest |x| / |x_k| seen over all RDBs on
+    representative tiles.  On the synthetic set it must land near the shipped defaults, keep the
+    measured tolerance, adapt to a net whose features are 8x larger, and refuse a non-fp8 handle."""
+    from s2sr.synth import synthetic_tiles
+    tiles = synthetic_tiles(4, 64, seed=3)
+    e = native.Engine(num_block=23, precision=native.PREC_FP8)
+    e.load_state_dict(synthetic_state_dict(23, seed=0))
+    xe, ge = e.calibrate_fp8(tiles, headroom=2.0)
+    print(f"calibrated exponents on the synthetic set: x {xe}, growth {ge} (defaults 3 / 5, which let the rarest outliers clip)")
+    assert 0 <= xe <= 4 and 2 <= ge <= 7
+    g = np.load(golden_dir / "g4_full_nets.npz")
+    d = np.abs(e.forward_f32(g["x"]) - g["y_b23"])
+    assert np.isfinite(d).all() and d.max() <= TOL_FP8_23
+    # a net with 8x conv_first (features 8x larger everywhere in the trunk): the scales follow, nothing clips
+    sd = synthetic_state_dict(23, seed=0)
+    sd["conv_first.weight"] = sd["conv_first.weight"] * 8
+    sd["conv_first.bias"] = sd["conv_first.bias"] * 8
+    e.load_state_dict(sd)
+    xe2, ge2 = e.calibrate_fp8(tiles, headroom=2.0)
+    assert xe2 <= xe - 2 and ge2 <= ge - 2, (xe2, ge2)
+    hp = native.Engine(num_block=23, precision=native.PREC_F16_HP)
+    hp.load_state_dict(sd)
+    a, b = e.forward_f32(g["x"]), hp.forward_f32(g["x"])
+    rel = np.abs(a - b).max() / np.abs(b).max()
+    print(f"8x features: exponents x {xe2}, growth {ge2}; fp8 vs hp rel err {rel:.3e}")
+    assert np.isfinite(a).all() and rel <= 2e-2
+    with pytest.raises(native.S2srError):
+        hp.calibrate_fp8(tiles)
+    e.close(); hp.close()
