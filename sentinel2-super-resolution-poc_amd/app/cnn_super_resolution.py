@@ -149,6 +149,10 @@ def _engine_for(state_dict, num_block: int, device_index: int, fingerprint: str)
             eng = native.Engine(num_block=num_block, device=device_index, precision=prec,
                                 group=int(os.environ.get("S2SR_GROUP", "0")))
             eng.load_blob(flatten_state_dict(state_dict, num_block))
+            if prec == native.PREC_FP8 and not (os.environ.get("S2SR_FP8_XEXP") or os.environ.get("S2SR_FP8_GEXP")):
+                # activation scales of the fp8 trunk from data: a few imagery-like tiles through THIS checkpoint
+                from s2sr.synth import synthetic_tiles
+                eng.calibrate_fp8(synthetic_tiles(4, 64, seed=0), headroom=2.0)
             _ENGINES[key] = eng
         return eng
 
