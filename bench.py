@@ -136,13 +136,22 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {a.gpus}")
+    # Rehearsal knobs for one-GPU boxes (never set by the driver): S2SR_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # S2SR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU) -- the multi-rank control flow of this file
+    # (broadcast, double-buffered steps, communication stream, max-reduce of the time) then runs with N > 1 on one card.
+    if os.environ.get("S2SR_BENCH_SAME_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1 or os.environ.get("S2SR_FORCE_DIST") == "1":   # the env knob rehearses the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+        backend = os.environ.get("S2SR_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- weights: rank 0 builds the blob, RCCL broadcast over xGMI ----------------------------
     nparam = num_params(NUM_BLOCK)

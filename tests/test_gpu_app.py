@@ -225,3 +225,31 @@ def test_farm_sr_on_fp8_trunk(monkeypatch, tmp_path):
     assert ia.shape == ib.shape == (96, 128, 3) and not np.array_equal(ia, ib) and d.max() <= 48 and d.mean() < 3.0
     import app.cnn_super_resolution as m
     assert len({k[2] for k in m._ENGINES}) >= 2          # two engines: default precision and fp8
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's N > 1 control flow (weight broadcast from rank 0, double-buffered steps with the all-gather on a
+    communication stream, max-over-ranks timing, one JSON line from rank 0) with TWO ranks on this one GPU: RCCL refuses two
+    ranks on one device, so the rehearsal runs the collectives over gloo (S2SR_BENCH_BACKEND / S2SR_BENCH_SAME_DEVICE are
+    rehearsal knobs the driver never sets).  Real N > 1 RCCL runs need a multi-GPU node."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, S2SR_BENCH_SAME_DEVICE="1", S2SR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(repo / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(repo))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "RCCL all-gather" in d["config"]["workload"] and "cpu_baseline" not in d
+    assert d["roofline"]["timed_pass"]["graph_replays"] >= 1
