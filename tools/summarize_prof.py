@@ -56,13 +56,17 @@ FAM = {"hp": {"rdb_conv1-4": ("conv_trunk_f16<1, 8, 3, 0", 18874368), "rdb_conv5
                "rdb_conv5_rrdb": ("conv_trunk_f8<2, 4, 4, 2", 41943040)}}
 for mode, fams in FAM.items():
     for fam, (pat, alg) in fams.items():
-        for k, cs in pmc.get(mode, {}).items():
-            if pat in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-                fk = cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1]
-                wk = cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1]
-                ent = {"kernel": k, "images_per_launch": IMGS, "fetch_kib_raw": round(fk), "write_kib": round(wk),
-                       "hbm_bytes_per_image": round((2 * fk + wk) * 1024 / IMGS), "algorithmic_bytes_per_image_mean": alg}
-                summary[("" if mode == "hp" else "fp8:") + fam] = ent
+        # a family can span several template instances (fp8 conv1-3 keep weights resident, conv4 streams them):
+        # pool their counters so the per-launch mean covers the same launches as the algorithmic mean
+        ks = [k for k, cs in pmc.get(mode, {}).items() if pat in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs]
+        if not ks:
+            continue
+        fs = [sum(pmc[mode][k][c][i] for k in ks) for c in ("FETCH_SIZE", "WRITE_SIZE") for i in (0, 1)]
+        fk, wk = fs[0] / fs[1], fs[2] / fs[3]
+        summary[("" if mode == "hp" else "fp8:") + fam] = {
+            "kernel": " + ".join(sorted(ks)), "dispatches": fs[1], "images_per_launch": IMGS, "fetch_kib_raw": round(fk),
+            "write_kib": round(wk), "hbm_bytes_per_image": round((2 * fk + wk) * 1024 / IMGS),
+            "algorithmic_bytes_per_image_mean": alg}
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 print("== pmc_summary.json")
 print(json.dumps(summary, indent=1))
