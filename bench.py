@@ -289,12 +289,19 @@ def main():
                                   "scaled_to_group": imgs}
             except Exception:
                 traffic = None
-        # the byte-side ceiling of a layer-by-layer schedule: arithmetic intensity (algorithmic FLOP / algorithmic
-        # HBM byte of the family) x the 6.3 TB/s a streaming kernel achieves on this part (MI355X_MICROARCH.md)
-        HBM_ACHIEVABLE_TBS = 6.3
+        # Which roof binds the dominant kernel: its arithmetic intensity (algorithmic FLOP / algorithmic HBM byte of a
+        # layer-by-layer schedule; measured traffic is within 3-4 % of that, profiles/pmc_summary.json) against the
+        # machine balance.  fp16 RDB convs: 224-260 FLOP/B against 2500/8 = 312 -> HBM is the lower roof; fp8: 400-450
+        # against 5000/8 = 625 -> HBM again.  The no-MFMA diagnostic builds (S2SR_DIAG_NOMFMA, profiles/
+        # r02_trunk_anatomy.txt section 8) agree: with every MFMA removed the same kernels still take 70-86 % of their time.
+        HBM_PEAK_GBS = 8000.0        # spec peak, MI355X_MICROARCH.md
+        HBM_ACHIEVABLE_TBS = 6.3     # what a streaming copy achieves on this part (same guide)
 
         def hbm_ceiling(v):
             return v["flops"] / v["bytes"] * HBM_ACHIEVABLE_TBS if v["bytes"] else None
+        hbm_roof_tflops = d["flops"] / d["bytes"] * HBM_PEAK_GBS / 1e3
+        alg_gbs = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+        hbm_bound = hbm_roof_tflops < PEAK
         line = {
             "metric": "SR megapixels/sec (whole node) on 256x256 RGB tiles, x4",
             "value": round(value, 2), "unit": "SR-MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -317,13 +324,20 @@ def main():
                                      "4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference, u8 within 1 LSB (93-95 % of bytes identical) -- NOT inside the 1e-3 tolerance"
                                      if a.precision == "fp8" else
                                      "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference")},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1),
-                         "peak": PEAK, "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4),
+            "roofline": {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
+                         "achieved": round(alg_gbs, 1) if hbm_bound else round(achieved, 1),
+                         "peak": HBM_PEAK_GBS if hbm_bound else PEAK, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                         "frac": round(alg_gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(achieved / PEAK, 4),
+                         "arithmetic_intensity_FLOP_per_B": round(d["flops"] / d["bytes"], 1),
+                         "machine_balance_FLOP_per_B": round(PEAK * 1e3 / HBM_PEAK_GBS, 1),
+                         "mfma": {"achieved": round(achieved, 1), "peak": PEAK, "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4),
+                                  "hbm_roof_TFLOP_per_s": round(hbm_roof_tflops, 1)},
                          "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                          "hbm_ceiling_TFLOP_per_s": round(hbm_ceiling(d), 1),
                          "frac_of_hbm_ceiling": round(achieved / hbm_ceiling(d), 4),
-                         "binds": "mfma issue + HBM bytes: see DESIGN.md section 4 (ceilings per family below)",
+                         "hbm_ceiling_note": "hbm_ceiling = arithmetic intensity x 6.3 TB/s (streaming-copy rate); the trunk kernels with their "
+                                             "MFMAs compiled out run at 5.1-5.4 TB/s algorithmic (profiles/r02_trunk_anatomy.txt section 8)",
                          "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
                          "stats_pass": {"every": PROF_EVERY, "ms_per_step": round(dt_prof / a.steps * 1e3, 3),
                                         "note": "separate pass after the timed region, direct launches + hipEvents"},
@@ -333,6 +347,7 @@ def main():
                          "families": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
                                           "TFLOP_per_s": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["total_ms"] else 0,
                                           "alg_GB_per_s": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else 0,
+                                          "frac_of_hbm_peak": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v["total_ms"] else 0,
                                           "hbm_ceiling_TFLOP_per_s": round(hbm_ceiling(v), 1) if v["flops"] and v["bytes"] else None}
                                       for k, v in stats.items() if v["launches"]}},
         }

@@ -44,6 +44,10 @@
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
+#ifndef S2SR_DIAG_NOMFMA
+#define S2SR_DIAG_NOMFMA 0      // timing diagnostic, both kernels: 1 = issue no MFMA (results are wrong).  What is left is the memory
+                                // side of the kernel: profiles/r02_trunk_anatomy.txt section 8
+#endif
 
 namespace s2sr {
 
@@ -403,6 +407,15 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                 if (np < 0 || np >= NP) continue;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+#if S2SR_DIAG_NOMFMA
+                    // timing diagnostic only (wrong results): the fragment reads stay alive, no MFMA is issued
+                    if (FIRST && dx == 0 && dy == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[ct][np][i] = 0.0f;
+                    }
+                    asm volatile("" : "+a"(acc[ct][np]) : "v"(acol[dx][dy][ct]), "v"(breg[t % 6]));
+                    continue;
+#endif
                     if (FIRST && dx == 0 && dy == 0) {
                         if (kBiasC) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
                         else mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
@@ -680,11 +693,17 @@ struct TG8 {
 
 // WV = 4: one wave per SIMD (512 registers).  WV = 8 (conv1-4 form): two waves per SIMD with 256 registers each -- the fp8
 // form is bound by ONE wave's issue port (PMC: 47 % of wave cycles issuing, 35 % MFMA busy), which a second wave doubles.
-template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0>
-__global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParams p) {
+// PROD = 1 (conv1-4 form, WV = 4): a FIFTH wave issues every LDS-DMA of the workgroup and nothing else.  With the MFMAs
+// compiled out (S2SR_DIAG_NOMFMA) these kernels still take 73 % of their time: they run against the memory system, whose
+// back-pressure stalls a DMA instruction at issue -- and, the wave being in-order, every MFMA behind it.  A wave that only
+// loads can sit in that stall for free; the four compute waves then only ever wait at the step barrier for data.
+// (Two waves share one SIMD: 256 registers per wave, which the conv1-4 form fits; conv5 and the fp16 kernels do not.)
+template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0, int PROD = 0>
+__global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trunk_f8(const ConvParams p) {
     using G = TG8<CT, NP, RS, WV, NPL>;
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert((EPI == EPI_LRELU && CT == 1) || (kTrunk && CT == 2), "conv1-4: 32 couts; conv5: 64 couts");
+    static_assert(PROD == 0 || (PROD == 1 && WV == 4 && !kTrunk), "loader wave: conv1-4 form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -792,6 +811,66 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
         glds16<false>(wS, zero ? (uint32_t)(G::WI * 1024) : lane16w + (uint32_t)sl * (WV * 1024) - back, mW + (uint32_t)sl * (WV * 1024) - back);
     };
 
+    // ---- the loader wave (PROD): the whole workgroup's DMA schedule, one barrier per pair-step like everybody else
+    if (PROD && wave == WV) {
+        uint32_t loffP[G::PI];                                   // my 16 bytes of piece jj of a plane
+#pragma unroll
+        for (int jj = 0; jj < G::PI; ++jj) {
+            const int i = jj * 64 + lane;
+            int q = i >> 1;
+            if (q >= G::SPX) q = 0;
+            const int ry = q / G::SW, rx = q - ry * G::SW;
+            const int h2 = (i & 1) ^ ((rx >> 3) & 1);
+            loffP[jj] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
+        }
+        auto issue_slabs = [&](uint32_t slot0) __attribute__((always_inline)) {     // the pair under the slab cursor -> slots slot0, slot0 + 1
+            slab_next();
+            uint32_t s1 = slot0 + 1;
+            if (s1 == (uint32_t)RS) s1 = 0;
+            const uint32_t tA = lds0 + slot0 * G::PLANE, tB = lds0 + s1 * G::PLANE;
+#pragma unroll
+            for (int jj = 0; jj < G::PI; ++jj) glds16<false>(sA, loffP[jj], tA + (uint32_t)jj * 1024);
+#pragma unroll
+            for (int jj = 0; jj < G::PI; ++jj) glds16<false>(sB, ph_slab ? 0u : loffP[jj], tB + (uint32_t)jj * 1024);
+        };
+        auto issue_wts = [&](uint32_t wslot) __attribute__((always_inline)) {       // the pair under the weight cursor -> weight slot wslot
+            wts_next();
+            const uint32_t tW = lds0 + G::WOFF + wslot * G::WBYTES;
+#pragma unroll
+            for (int i = 0; i < 2 * G::WI; ++i)
+                glds16<false>(wS, (ph_wts && i >= G::WI) ? (uint32_t)(G::WI * 1024) : (uint32_t)lane * 16 + (uint32_t)i * 1024, tW + (uint32_t)i * 1024);
+        };
+        issue_slabs(0);
+        if (G::WRES) {
+            const int npieces = p.nstage * G::WI;
+            for (int i = 0; i < npieces; ++i)
+                glds16<false>((const char*)p.wpack, (uint32_t)lane * 16 + (uint32_t)i * 1024, lds0 + G::WOFF + (uint32_t)i * 1024);
+        } else {
+            issue_wts(0);
+            issue_wts(1);
+        }
+#pragma unroll
+        for (int a = 1; a < G::AHEAD; ++a) issue_slabs((uint32_t)(2 * a));
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const int total_steps = my_tiles * NSTEP;
+        uint32_t slot = 0, wsl = 0;
+        for (int k = 0; k < total_steps; ++k) {
+            uint32_t dma_slot = slot + 2 * G::AHEAD;
+            while (dma_slot >= (uint32_t)RS) dma_slot -= RS;
+            issue_slabs(dma_slot);                               // pair-step k + AHEAD, where pair-step k - 1 was (barrier k - 1 released it)
+            // landed before barrier k: everything older than this iteration's slabs, if those run more than one step ahead
+            constexpr int NPW = (G::AHEAD >= 2) ? 2 * G::PI : 0;
+            static_assert(NPW < 64, "vmcnt field is 6 bits");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPW) : "memory");
+            if (!G::WRES) issue_wts(wsl);                        // pair-step k + 2, into the weight slot barrier k released
+            slot += 2;
+            if (slot >= (uint32_t)RS) slot -= RS;
+            wsl ^= 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
     // ---- fragment addresses: per-lane base + immediate.  b0 / b1 = logical 16-B halves 0 / 1 of pixel (row, pcol + dx)
     uint32_t b0base[3], b1base[3];
 #pragma unroll
@@ -834,7 +913,7 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
     uint32_t cur_slot = 0;        // slab ring slot of the current pair's first plane
     uint32_t cur_w = 0;           // weight slot of the current pair
     uint32_t cur_st = 0;          // pair-step inside the patch
-    {
+    if (!PROD) {
         slab_next();              // slabs of pair-step 0
         dma_targets(0, 0);
 #pragma unroll
@@ -864,7 +943,8 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
             for (int sl = 0; sl < G::PWS; ++sl) dma_slab(sl);
         }
     }
-    wait_release_barrier<G::NW>();
+    if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the loader waited for the data
+    else wait_release_barrier<G::NW>();
     auto lane_slab_of = [&](uint32_t slot0) __attribute__((always_inline)) -> uint32_t {
         uint32_t s1 = slot0 + 1;
         if (s1 == (uint32_t)RS) s1 = 0;
@@ -917,8 +997,10 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
         if (nxt_st == (uint32_t)NSTEP) nxt_st = 0;
         const uint32_t wo = G::WRES ? cur_st * (uint32_t)G::WBYTES : cur_w * G::WBYTES;
         const uint32_t won = G::WRES ? nxt_st * (uint32_t)G::WBYTES : (cur_w ^ 1) * G::WBYTES;
-        slab_next();
-        dma_targets(dma_slot, cur_w);
+        if (!PROD) {
+            slab_next();
+            dma_targets(dma_slot, cur_w);
+        }
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
@@ -928,9 +1010,10 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
                 // step's slab DMA (one pair-step's worth) may stay in flight.  With the 4-slot ring the needed slabs are this
                 // step's own: everything drains (vmcnt completes in issue order).
                 constexpr int NEPI = (G::AHEAD >= 2) ? G::NW + CT * NP : 0;      // conv1-4 form: CT*NP plane stores per wave
-                if (FIRST && !first_patch && G::AHEAD >= 2) wait_release_barrier<NEPI>();
+                if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // my only vector-memory traffic are stores
+                else if (FIRST && !first_patch && G::AHEAD >= 2) wait_release_barrier<NEPI>();
                 else wait_release_barrier<G::NW>();
-                if (!G::WRES) wts_next();                     // two pair-steps ahead: into the weight slot this barrier released
+                if (!G::WRES && !PROD) wts_next();            // two pair-steps ahead: into the weight slot this barrier released
             }
             {
                 const int u = t + 3;
@@ -950,8 +1033,8 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
             // DMA: the slabs AHEAD pair-steps ahead in front of the barrier step, the weights two pair-steps ahead behind it
 #pragma unroll
             for (int i = 0; i < G::PWS; ++i)
-                if ((i * (G::T - 3)) / G::PWS == t) dma_slab(i);
-            if (t >= G::T - 3) {
+                if (!PROD && (i * (G::T - 3)) / G::PWS == t) dma_slab(i);
+            if (!PROD && t >= G::T - 3) {
 #pragma unroll
                 for (int i = 0; i < G::PWW; ++i)
                     if (G::T - 3 + (i * 3) / G::PWW == t) dma_wts(i);
@@ -962,6 +1045,15 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
                 if (np < 0 || np >= NP) continue;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
+#if S2SR_DIAG_NOMFMA
+                    // timing diagnostic only (wrong results): the fragment reads stay alive, no MFMA is issued
+                    if (FIRST && dx == 0 && dy == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[ct][np][i] = 0.0f;
+                    }
+                    asm volatile("" : "+a"(acc[ct][np]) : "v"(acol[dx][dy][ct]), "v"(breg[t % 6]));
+                    continue;
+#endif
                     if (FIRST && dx == 0 && dy == 0) {
                         if (kBiasC) mfma8_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb, bacc[kBiasC ? ct : 0]);
                         else mfma8_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6], sa[ct], sb);
@@ -1144,12 +1236,12 @@ __global__ void __launch_bounds__(WV * 64, WV / 4) conv_trunk_f8(const ConvParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0>
+template <int CT, int NP, int RS, int EPI, int WV = 4, int NPL = 0, int PROD = 0>
 hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
     using G = TG8<CT, NP, RS, WV, NPL>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS rings do not fit");
     static_assert(G::NW >= 0 && G::NW < 64, "vmcnt field is 6 bits");
-    auto kern = conv_trunk_f8<CT, NP, RS, EPI, WV, NPL>;
+    auto kern = conv_trunk_f8<CT, NP, RS, EPI, WV, NPL, PROD>;
     if (NPL > 0 && p.nstage > NPL) return hipErrorInvalidValue;   // resident weights: the conv's planes must fit the LDS block
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
@@ -1184,7 +1276,7 @@ hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
     const int ntiles = q.tilesX * q.tilesY * p.N;
     int grid = ncu & ~7;
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WV * 64), G::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((WV + PROD) * 64), G::LDS_BYTES, st, q);
     return hipGetLastError();
 }
 
@@ -1258,7 +1350,11 @@ hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_
         // Measured on one box, conv1-4 per 5 steps: 108.7 / 109.8 / 111.9 ms -- +1 %, nothing like the -18 % a "no weight DMA"
         // diagnostic suggested (that one read zeros as weights, and an MFMA fed zeros draws less power: the chip clocked higher).
         static const int stream_w = [] { const char* e = getenv("S2SR_FP8_WSTREAM"); return e ? atoi(e) : 0; }();
+        // the loader-wave form (conv_trunk_f8 PROD) is the default: 77.5 against 79.8 us per conv1-4 launch of 32 tiles on one box,
+        // A/B/A/B (+3 %; the no-MFMA floor of either form is 58 us).  S2SR_FP8_LOADER=0 selects the four-wave forms below.
+        static const bool loader = [] { const char* e = getenv("S2SR_FP8_LOADER"); return !e || atoi(e) != 0; }();
         if (w8) return launch_trunk8_t<1, 2, 6, EPI_LRELU, 8>(p, st);
+        if (loader) return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4, 1>(p, st) : launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 0, 1>(p, st);
         if (stream_w == 1 || (stream_w == 0 && p.nstage > 4)) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
         return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4>(p, st) : launch_trunk8_t<1, 4, 4, EPI_LRELU, 4, 6>(p, st);
     }
