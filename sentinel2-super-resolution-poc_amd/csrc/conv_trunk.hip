@@ -44,6 +44,10 @@
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
+#ifndef S2SR_DIAG_NOLO
+#define S2SR_DIAG_NOLO 0        // numerics diagnostic (tools/nolo_probe.sh): the fp16 trunk carried WITHOUT its lo half.  Measured: max-abs
+                                // 2.2e-3 .. 3.4e-3 instead of 7e-5 .. 1.8e-4 -- the 256-384 B per pixel and RDB the pair costs are what the 1e-3 costs
+#endif
 #ifndef S2SR_DIAG_NOMFMA
 #define S2SR_DIAG_NOMFMA 0      // timing diagnostic, both kernels: 1 = issue no MFMA (results are wrong).  What is left is the memory
                                 // side of the kernel: profiles/r02_trunk_anatomy.txt section 8
@@ -525,7 +529,12 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
+#if S2SR_DIAG_NOLO
+                            const float t = th[i];
+                            if (EPI == EPI_RDB5_RRDB) rs[i] = half4_to_float(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g])[i];
+#else
                             const float t = __fadd_rn(th[i], tl[i]);
+#endif
                             v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), t);
                             if (EPI == EPI_RDB5_RRDB) v[i] = __fadd_rn(__fmul_rn(v[i], 0.2f), rs[i]);
                         }
@@ -537,7 +546,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     if (kTrunk) {
                         f16x4 lv;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) lv[i] = (f16)__fsub_rn(v[i], (float)hv[i]);
+                        for (int i = 0; i < 4; ++i) lv[i] = S2SR_DIAG_NOLO ? (f16)0.0f : (f16)__fsub_rn(v[i], (float)hv[i]);
                         lpk[g] = __builtin_bit_cast(u32x2, lv);
                     }
                 }
