@@ -316,8 +316,8 @@ def main():
                        "flop_note": "TFLOP/s figures count the reference net's FLOPs (2*9*Cin*Cout per output pixel); the two "
                                     "up-convs execute 4/9 of theirs (sub-pixel form), 2.3 % of the net",
                        "group": a.group, "weights": "seeded synthetic RealESRGAN_x4plus shapes (seed 0)",
-                       "precision": ("fp16 MFMA operands, fp32 accumulate, trunk as fp16 hi/lo pair; the 6 convs outside the "
-                                     "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 7e-5..1.2e-4 vs the fp32 reference"
+                       "precision": ("fp16 MFMA operands, fp32 accumulate, trunk as an (fp16 hi, e4m3 lo) pair; the 6 convs outside the "
+                                     "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 8e-5..1.9e-4 vs the fp32 reference"
                                      if a.precision == "hp" else
                                      "the 345 RDB convs on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, "
                                      "per-tensor-kind activation scales, fp32 accumulate, fp16 trunk); head/tail convs as in hp: measured max-abs "

@@ -46,7 +46,7 @@
 #endif
 #ifndef S2SR_DIAG_NOLO
 #define S2SR_DIAG_NOLO 0        // numerics diagnostic (tools/nolo_probe.sh): the fp16 trunk carried WITHOUT its lo half.  Measured: max-abs
-                                // 2.2e-3 .. 3.4e-3 instead of 7e-5 .. 1.8e-4 -- the 256-384 B per pixel and RDB the pair costs are what the 1e-3 costs
+                                // 2.2e-3 .. 3.4e-3 instead of 7e-5 .. 1.8e-4: the pair is what the 1e-3 costs (its lo half needs only e4m3, see the epilogue)
 #endif
 #ifndef S2SR_DIAG_NOMFMA
 #define S2SR_DIAG_NOMFMA 0      // timing diagnostic, both kernels: 1 = issue no MFMA (results are wrong).  What is left is the memory
@@ -155,7 +155,7 @@ __device__ __forceinline__ void wait_release_barrier() {
 
 template <int EPI, int CT, int NP>
 struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3x3.hip EpiStores)
-    static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : CT * 4 * NP;
+    static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : CT * 3 * NP;     // conv5: two fp16 blocks of x + one e4m3 plane of lo per 32 couts
 };
 
 template <int CT, int NP, int R, int EPI, bool TRACE>
@@ -333,22 +333,22 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 
     // conv5: the trunk-lo operands of the patch's own pixels are requested at the START of the patch's last stage, straight
     // into AGPRs, and arrive under its MFMAs instead of stalling the epilogue for an HBM round trip
-    u32x2 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1][4];
+    // The lo half is an e4m3 plane pair (32 channels per plane, 32 bytes per pixel: e4m3(lo * 2^lo_exp)); a lane fetches 16
+    // bytes of its pixel (half-wave 0: channels 0-15 of the plane, half-wave 1: 16-31) and two v_permlane32_swap hand each
+    // lane the four dwords that match its accumulator registers -- the store path of the fp8 kernel run backwards.
+    f32x4 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1];
     auto prefetch_lo = [&](int it) __attribute__((always_inline)) {
         const int tile = it * nwg + slot_in_round;
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
         const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
-        const size_t ln = (size_t)n * 4 * oblk;
+        const size_t ln = (size_t)n * 2 * oblk;
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const size_t opix = (size_t)(ty * G::TH + wave * NP + np + 1) * p.Wp + (tx * G::TW + pcol + 1);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g] =
-                        asm_load8(p.xh_in + ln + (size_t)(ct * 2 + (g >> 1)) * oblk + opix * 32 + (g & 1) * 16 + hh * 8);   // xh_in: the trunk lo coming in
+                lo_old[kTrunk ? ct : 0][kTrunk ? np : 0] = asm_load16(p.xh_in + ln + (size_t)ct * oblk + opix * 32 + hh * 16);   // xh_in: the trunk lo coming in
         }
     };
 
@@ -462,8 +462,23 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             ok[np] = (y < p.H) && (x < p.W);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
-        const size_t ln = (size_t)n * 4 * oblk;   // image offset inside the fp16 lo tensors, bytes
-        u32x2 rhi[EPI == EPI_RDB5_RRDB ? CT : 1][4], rlo[EPI == EPI_RDB5_RRDB ? CT : 1][4];   // RRDB skip as an fp16 pair
+        const size_t ln = (size_t)n * 2 * oblk;   // image offset inside the e4m3 lo tensors, bytes
+        u32x2 rhi[EPI == EPI_RDB5_RRDB ? CT : 1][4];   // RRDB skip: fp16 hi ...
+        f32x4 rlo[EPI == EPI_RDB5_RRDB ? CT : 1];      // ... + e4m3 lo (16 bytes per lane, see lo_old)
+        const float lo_dec = __builtin_ldexpf(1.0f, -p.lo_exp), lo_enc = __builtin_ldexpf(1.0f, p.lo_exp);
+        // the four dwords of a lane's channel groups out of the 16 bytes it fetched (q[g] = channels 8g+4hh.. of the plane)
+        auto unswap = [&](const f32x4& o, uint32_t (&q)[4]) __attribute__((always_inline)) {
+            const u32x4 u = __builtin_bit_cast(u32x4, o);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(u[0], u[1], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(u[2], u[3], false, false);
+            q[0] = s0[0]; q[2] = s0[1]; q[1] = s1[0]; q[3] = s1[1];
+        };
+        auto e4m3x4_to_float = [&](uint32_t w) __attribute__((always_inline)) -> f32x4 {
+            f32x4 r;
+            r[0] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0) * lo_dec; r[1] = __builtin_amdgcn_cvt_f32_fp8((int)w, 1) * lo_dec;
+            r[2] = __builtin_amdgcn_cvt_f32_fp8((int)w, 2) * lo_dec; r[3] = __builtin_amdgcn_cvt_f32_fp8((int)w, 3) * lo_dec;
+            return r;
+        };
         const size_t sn = (size_t)n * p.xh_img;   // image offset inside the skip-hi tensor, bytes
         if (kTrunk) {
             // the prefetched trunk lo: only the last stage's DMA instructions are younger
@@ -472,8 +487,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             for (int np = 0; np < NP; ++np)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) asm_land(lo_old[ct][np][g]);
+                    asm_land(lo_old[ct][np]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -485,21 +499,25 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     for (int g = 0; g < 4; ++g) {
                         const size_t off = (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8;
                         rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g] = asm_load8(p.xh_skip + sn + off);
-                        rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g] = asm_load8(p.lo_skip + ln + off);
                     }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    rlo[EPI == EPI_RDB5_RRDB ? ct : 0] = asm_load16(p.lo_skip + ln + (size_t)ct * oblk + opix[np] * 32 + hh * 16);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        asm_land(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-                        asm_land(rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-                    }
+                    for (int g = 0; g < 4; ++g) asm_land(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) asm_land(rlo[EPI == EPI_RDB5_RRDB ? ct : 0]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                u32x2 hpk[4], lpk[4];
+                u32x2 hpk[4];
+                uint32_t lq8[4], loq[4], rlq[4];
+                if (kTrunk) unswap(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0], loq);
+                if (EPI == EPI_RDB5_RRDB) unswap(rlo[EPI == EPI_RDB5_RRDB ? ct : 0], rlq);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -520,10 +538,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(acc[ct][np][4 * g + i], bv[ct][4 * g + i]);
                         // t = hi + lo (exact in fp32); hi was captured from LDS: block ct*2 + (g>>1), half g&1
                         const f32x4 th = half4_to_float(hi_cap[kTrunk ? (ct * 2 + (g >> 1)) & 3 : 0][kTrunk ? np : 0][g & 1]);
-                        const f32x4 tl = half4_to_float(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0][g]);
+                        const f32x4 tl = e4m3x4_to_float(loq[g]);
                         f32x4 rs;
                         if (EPI == EPI_RDB5_RRDB) {
-                            const f32x4 a = half4_to_float(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]), b = half4_to_float(rlo[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
+                            const f32x4 a = half4_to_float(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]), b = e4m3x4_to_float(rlq[g]);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) rs[i] = __fadd_rn(a[i], b[i]);     // the trunk at the RRDB's input (exact in fp32)
                         }
@@ -544,10 +562,15 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     for (int i = 0; i < 4; ++i) hv[i] = (f16)v[i];
                     hpk[g] = __builtin_bit_cast(u32x2, hv);
                     if (kTrunk) {
-                        f16x4 lv;
+                        // lo = v - fp16(v), kept as e4m3(lo * 2^lo_exp): 4 significant bits of it are what the 1e-3 needs
+                        // (measured: max-abs 8.8e-5 .. 1.85e-4 against 7.0e-5 .. 1.8e-4 with an fp16 lo, 2.2e-3 .. 3.4e-3 without one)
+                        float q[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) lv[i] = S2SR_DIAG_NOLO ? (f16)0.0f : (f16)__fsub_rn(v[i], (float)hv[i]);
-                        lpk[g] = __builtin_bit_cast(u32x2, lv);
+                        for (int i = 0; i < 4; ++i)
+                            q[i] = S2SR_DIAG_NOLO ? 0.0f : __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[i], (float)hv[i]), lo_enc), -448.0f, 448.0f);
+                        int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                        w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w8, true);
+                        lq8[g] = (uint32_t)w8;
                     }
                 }
                 // pair the half-waves: one 16-B store per 16-channel block, 1 KiB contiguous per wave-instruction
@@ -559,14 +582,13 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     u32x4 o;
                     o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
                     *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = o;
-                    if (kTrunk) {
-                        u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
-                        const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
-                        const auto q1 = __builtin_amdgcn_permlane32_swap(llo[1], lhi[1], false, false);
-                        u32x4 ol;
-                        ol[0] = q0[0]; ol[1] = q1[0]; ol[2] = q0[1]; ol[3] = q1[1];
-                        *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(ct * 2 + bk) * oblk + opix[np] * 32 + hh * 16 : trash) = ol;
-                    }
+                }
+                if (kTrunk) {   // the e4m3 lo plane: after the swaps half-wave 0 holds dwords 0-3 of the pixel, half-wave 1 dwords 4-7
+                    const auto q0 = __builtin_amdgcn_permlane32_swap(lq8[0], lq8[2], false, false);
+                    const auto q1 = __builtin_amdgcn_permlane32_swap(lq8[1], lq8[3], false, false);
+                    u32x4 ol;
+                    ol[0] = q0[0]; ol[1] = q0[1]; ol[2] = q1[0]; ol[3] = q1[1];
+                    *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)ct * oblk + opix[np] * 32 + hh * 16 : trash) = ol;
                 }
             }
         }
@@ -625,7 +647,8 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     // operand shapes the kernel's indexing assumes (a violation would read or write outside the tensors)
     if (p.nstage < 1 || p.nstage > 12 || p.sHp != p.Hp || p.sWp != p.Wp || p.Hp < p.H + 2 || p.Wp < p.W + 2) return hipErrorInvalidValue;
     if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 5 || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
-        return hipErrorInvalidValue;   // T = trunk lo out, xh_in = trunk lo in, (xh_skip, lo_skip) = the RRDB's input as an fp16 pair
+        return hipErrorInvalidValue;   // T = trunk lo out, xh_in = trunk lo in (e4m3 planes), (xh_skip, lo_skip) = the RRDB's input as an (fp16, e4m3) pair
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.lo_exp < 6 || p.lo_exp > 18)) return hipErrorInvalidValue;
     if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;   // slabs of edge patches stay inside the plane
     if (!p.src || !p.dst || !p.wpack || !p.bias || !p.trash) return hipErrorInvalidValue;
     ConvParams q = p;

@@ -49,8 +49,8 @@ struct Workspace {
                                          // through an RRDB (rdb k reads D[k], writes the next x into D[(k+1)%3]), so the
                                          // RRDB's input D[0] is still there when rdb3's conv5 needs it as the skip
     char *U0 = nullptr;                  // 4 blocks
-    char *T = nullptr;                   // trunk lo (fp16, 4 blocks) = Tr[0]
-    char *Tr[3] = {nullptr, nullptr, nullptr};  // trunk lo of D[0..2]
+    char *T = nullptr;                   // trunk lo as fp16 (4 blocks): conv_first writes it, conv_body's packer reads it (8-wave path: every conv5 too)
+    char *Tr[3] = {nullptr, nullptr, nullptr};  // one-wave-per-SIMD path: trunk lo of D[0..2] as e4m3(lo * 2^lo_exp), 2 planes of 32 channels
     float *R = nullptr, *F = nullptr;    // fp32 RRDB skip / global skip (8 blocks of 8)
     // 2x and 4x tensors, 4 blocks each
     char *U1 = nullptr, *U2 = nullptr, *U3 = nullptr;
@@ -119,6 +119,8 @@ struct s2sr_handle {
     float* d_calib = nullptr;     // fp8 calibration: [0] max |x| of the trunk, [1] max |x_k| of the growth planes (device)
     bool fp8_hp_tail = false;     // S2SR_PREC_FP8: the six head / tail convs in plain fp16 (their ~2e-3 is below the trunk's e4m3
                                   // error) unless S2SR_FP8_TAIL=hp asks for the split-operand forms
+    int lo_exp = 12;              // fp16 modes, one-wave-per-SIMD trunk: the trunk's lo half as e4m3(lo * 2^lo_exp): exact to 4 bits for
+                                  // |x| < 2^(20 - lo_exp) = 256, clamped beyond (S2SR_LO_EXP)
     int fp8_x_exp = 3, fp8_g_exp = 5;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP); calibrated
                                         // on the synthetic set: profiles/r02_fp8_scale_sweep.txt (|x| up to 56, |x_k| up to 14 before clipping)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
@@ -220,8 +222,8 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     const size_t g = (size_t)G;
     const size_t nd = fp8 ? 0 : 12;     // the fp16 dense tensors are not used by the fp8 trunk
     const size_t oP0 = take(g * w.blk1), oD0 = take(g * nd * w.blk1), oD1 = take(g * nd * w.blk1), oD2 = take(g * nd * w.blk1),
-                 oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oT1 = take(g * (fp8 ? 0 : 4) * w.blk1),
-                 oT2 = take(g * (fp8 ? 0 : 4) * w.blk1), oR = take(g * 8 * w.blk1),
+                 oU0 = take(g * 4 * w.blk1), oT = take(g * 4 * w.blk1), oT0 = take(g * (fp8 ? 0 : 2) * w.blk1), oT1 = take(g * (fp8 ? 0 : 2) * w.blk1),
+                 oT2 = take(g * (fp8 ? 0 : 2) * w.blk1), oR = take(g * 8 * w.blk1),
                  oF = take(g * 8 * w.blk1), oU1 = take(g * 4 * w.blk2), oU2 = take(g * 4 * w.blk4),
                  oU3 = take(g * 4 * w.blk4);
     size_t oU0l = 0, oU1l = 0, oU2l = 0, oU3l = 0;
@@ -241,7 +243,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
     HIPCHK(h, hipDeviceSynchronize());
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.D[2] = w.base + oD2; w.U0 = w.base + oU0;
-    w.T = w.base + oT; w.Tr[0] = w.T; w.Tr[1] = w.base + oT1; w.Tr[2] = w.base + oT2; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
+    w.T = w.base + oT; w.Tr[0] = w.base + oT0; w.Tr[1] = w.base + oT1; w.Tr[2] = w.base + oT2; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
     if (hp) { w.U0lo = w.base + oU0l; w.U1lo = w.base + oU1l; w.U2lo = w.base + oU2l; w.U3lo = w.base + oU3l; w.T8 = w.base + oT8; }
     if (fp8) {
@@ -313,8 +315,9 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
     if (epi == EPI_LAST) bytes += px * 3.0 * ((p.out_u8 ? 1.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0));
     else bytes += px * cw.cout * 2.0;
-    if (epi == EPI_RDB5) bytes += px * 64 * 4.0;          // lo: fp16 read + write
-    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * (p.xh_skip ? 8.0 : 12.0);    // lo r/w + RRDB skip: fp16 pair read (trunk kernel) or fp32 R r/w
+    const bool lo8 = h->trunk_w4;                          // one-wave-per-SIMD trunk: lo as e4m3 planes (1 B per channel), else fp16
+    if (epi == EPI_RDB5) bytes += px * 64 * (lo8 ? 2.0 : 4.0);          // lo: read + write
+    if (epi == EPI_RDB5_RRDB) bytes += px * 64 * (p.xh_skip ? (lo8 ? 5.0 : 8.0) : 12.0);    // lo r/w + RRDB skip: (fp16 hi, lo) pair read (trunk kernel) or fp32 R r/w
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
@@ -368,7 +371,8 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
     int cur = 0;
     const char* trunk_hi = nullptr;   // fp16 x of the trunk after the body (conv_body's main operand)
     uint64_t trunk_hi_img = 0;
-    const char* trunk_lo = nullptr;   // its fp16 lo half
+    const char* trunk_lo = nullptr;   // its lo half: fp16 (4 blocks), or e4m3(lo * 2^trunk_lo_exp) planes when trunk_lo_exp >= 0
+    int trunk_lo_exp = -1;
     if (fp8) {
         // the trunk on e4m3 operands (conv_trunk.hip, conv_trunk_f8): D8[cur] planes [x(2) | x1 | x2 | x3 | x4]
         const int xe = h->fp8_x_exp, ge = h->fp8_g_exp;
@@ -414,6 +418,12 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
         // one-wave-per-SIMD trunk kernel: rdb r of every RRDB reads D[r] / Tr[r] and writes the next trunk (x, lo) into
         // D[(r+1)%3] / Tr[(r+1)%3]; rdb3's conv5 takes the RRDB skip from (D[0] x blocks, Tr[0]) -- still the RRDB's
         // input -- and overwrites exactly those pixels (same lane reads, then writes; nobody else touches D[0] then)
+        // The lo half travels as e4m3(lo * 2^lo_exp) planes (half the bytes; 4 significant bits of it keep the net inside 3e-4,
+        // DESIGN.md section 3): conv_first's fp16 lo is converted once on the way in.
+        {
+            Scope sc(h, st, F_MISC, 0.0, (double)n * w.Hp * w.Wp * (128.0 + 64.0));
+            HIPCHK(h, launch_xh_to_fp8(w.T, 4 * w.blk1, n, w.Hp, w.Wp, h->lo_exp, w.Tr[0], 2 * w.blk1, st));
+        }
         for (int blk = 0; blk < nb; ++blk)
             for (int r = 0; r < 3; ++r) {
                 const int nx = (r + 1) % 3;
@@ -426,11 +436,11 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
                 ConvParams p = b;
                 p.src = w.D[r]; p.src_img = 12 * w.blk1;
                 p.dst = w.D[nx]; p.dst_img = 12 * w.blk1;
-                p.xh_in = w.Tr[r]; p.T = w.Tr[nx];
+                p.xh_in = w.Tr[r]; p.T = w.Tr[nx]; p.lo_exp = h->lo_exp;
                 if (r == 2) { p.xh_skip = w.D[0]; p.xh_img = 12 * w.blk1; p.lo_skip = w.Tr[0]; }
                 if ((rc = run_conv(h, st, F_RDB5, h->convs[ci++], p, r == 2 ? EPI_RDB5_RRDB : EPI_RDB5, false))) return rc;
             }
-        trunk_hi = w.D[0]; trunk_hi_img = 12 * w.blk1; trunk_lo = w.Tr[0];
+        trunk_hi = w.D[0]; trunk_hi_img = 12 * w.blk1; trunk_lo = w.Tr[0]; trunk_lo_exp = h->lo_exp;
     } else {
         for (int blk = 0; blk < nb; ++blk)
             for (int r = 0; r < 3; ++r) {
@@ -454,7 +464,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
         p.src = trunk_hi; p.src_img = trunk_hi_img; p.dst = w.U0; p.dst_img = 4 * w.blk1;
         if (hp) {
             Scope sc(h, st, F_MISC, 0.0, (double)n * w.Hp * w.Wp * (256.0 + 128.0));
-            HIPCHK(h, launch_trunk_to_fp8(trunk_hi, trunk_hi_img, trunk_lo, 4 * w.blk1, n, w.Hp, w.Wp, w.T8, st));
+            HIPCHK(h, launch_trunk_to_fp8(trunk_hi, trunk_hi_img, trunk_lo, (trunk_lo_exp >= 0 ? 2 : 4) * w.blk1, trunk_lo_exp, n, w.Hp, w.Wp, w.T8, st));
             p.src_lo = w.T8; p.lo_img = 4 * w.blk1; p.T = w.U0lo;
         }
         if ((rc = run_conv(h, st, F_BODY, h->convs[ci++], p, EPI_BODY, false, hp))) return rc;
@@ -637,6 +647,10 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
+    if (const char* g = getenv("S2SR_LO_EXP")) {
+        const int v = atoi(g);
+        if (v >= 6 && v <= 18) h->lo_exp = v;
+    }
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
@@ -1415,7 +1429,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     p.src = D0; p.src_img = 12 * blk; p.nstage = cin / 16;
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
     p.T = T; p.R = Rr; p.F = Rr; p.trash = h->d_trash;
-    p.xh_in = T;   // conv_trunk_f16: trunk lo coming in (here read and written in place: timing only)
+    p.xh_in = T; p.lo_exp = h->lo_exp;   // conv_trunk_f16: trunk lo coming in (here read and written in place: timing only)
     p.dbg = getenv("S2SR_DBG") ? atoi(getenv("S2SR_DBG")) : 0;
     int epi;
     if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }

@@ -65,14 +65,36 @@ hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, fl
 // blocks 0..3, lo = the trunk-lo tensor); the split-operand kernel wants e4m3 planes of 32 channels
 // [lo*2^11 plane 0, plane 1, hi plane 0, plane 1] in the same padded geometry (halo pixels are zero
 // in both inputs, so the whole padded tensor is converted).  One thread = one pixel of one plane.
+// lo_e4m3_exp >= 0: the lo half arrives as e4m3(lo * 2^lo_e4m3_exp) planes already (the one-wave-per-SIMD trunk keeps it so);
+// it is rescaled to the 2^11 the split-operand kernel expects.
 __global__ void trunk_to_fp8_kernel(const char* __restrict__ hi, size_t hi_img, const char* __restrict__ lo, size_t lo_img,
-                                    int N, size_t ppx, char* __restrict__ out) {
+                                    int lo_e4m3_exp, int N, size_t ppx, char* __restrict__ out) {
     const size_t total = (size_t)N * 4 * ppx;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = i % ppx;
         const int plane = (int)((i / ppx) & 3);
         const int n = (int)(i / (4 * ppx));
         const bool is_hi = plane >= 2;
+        if (!is_hi && lo_e4m3_exp >= 0) {
+            const uint32_t* v = (const uint32_t*)(lo + (size_t)n * lo_img + (size_t)plane * ppx * 32 + pix * 32);
+            const float rs = ldexpf(1.0f, 11 - lo_e4m3_exp);
+            uint32_t o8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int w0 = (int)v[q];
+                const float f0 = __builtin_amdgcn_fmed3f(__builtin_amdgcn_cvt_f32_fp8(w0, 0) * rs, -448.0f, 448.0f);
+                const float f1 = __builtin_amdgcn_fmed3f(__builtin_amdgcn_cvt_f32_fp8(w0, 1) * rs, -448.0f, 448.0f);
+                const float f2 = __builtin_amdgcn_fmed3f(__builtin_amdgcn_cvt_f32_fp8(w0, 2) * rs, -448.0f, 448.0f);
+                const float f3 = __builtin_amdgcn_fmed3f(__builtin_amdgcn_cvt_f32_fp8(w0, 3) * rs, -448.0f, 448.0f);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(f0, f1, 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(f2, f3, w, true);
+                o8[q] = (uint32_t)w;
+            }
+            uint4* d8 = (uint4*)(out + ((size_t)n * 4 + plane) * ppx * 32 + pix * 32);
+            d8[0] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+            d8[1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+            continue;
+        }
         const char* src = (is_hi ? hi + (size_t)n * hi_img : lo + (size_t)n * lo_img) + (size_t)(2 * (plane & 1)) * ppx * 32 + pix * 32;
         const float scale = is_hi ? 1.0f : 2048.0f;
         uint32_t o[8];
@@ -95,11 +117,11 @@ __global__ void trunk_to_fp8_kernel(const char* __restrict__ hi, size_t hi_img, 
     }
 }
 
-hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int N, int Hp, int Wp, char* out,
+hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int lo_e4m3_exp, int N, int Hp, int Wp, char* out,
                                hipStream_t st) {
     const size_t ppx = (size_t)Hp * Wp, total = (size_t)N * 4 * ppx;
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(trunk_to_fp8_kernel, dim3(grid), dim3(256), 0, st, hi, hi_img, lo, lo_img, N, ppx, out);
+    hipLaunchKernelGGL(trunk_to_fp8_kernel, dim3(grid), dim3(256), 0, st, hi, hi_img, lo, lo_img, lo_e4m3_exp, N, ppx, out);
     return hipGetLastError();
 }
 

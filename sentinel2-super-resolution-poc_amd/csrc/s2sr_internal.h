@@ -83,6 +83,7 @@ struct ConvParams {
     uint64_t xh_img;         // bytes between images of the three
     const int32_t* wscale;   // [64] E8M0 bytes 127 - k_co of the per-output-channel weight scales 2^k_co
     int32_t x_exp, g_exp;    // activation scales: x planes hold e4m3(x * 2^x_exp), growth planes e4m3(x_k * 2^g_exp)
+    int32_t lo_exp;          // conv_trunk_f16 conv5: the trunk's lo half is stored as e4m3(lo * 2^lo_exp) planes (xh_in, T, lo_skip)
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
     int32_t dbg;                 // diagnostic only (timing ablations, results wrong): 1 weights DMA from one fixed piece,
@@ -137,7 +138,7 @@ hipError_t launch_tiles_overview(const uint8_t* d_child, int cnx, int cny, int o
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);
 hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB,
                                 int Hp, int Wp, hipStream_t st);
-hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int N, int Hp, int Wp, char* out,
+hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int lo_e4m3_exp, int N, int Hp, int Wp, char* out,
                                hipStream_t st);
 hipError_t launch_gather_windows(const uint8_t* d_img, int H, int W, const int32_t* d_rects, int T, int wh, int ww,
                                  uint8_t* d_tiles, hipStream_t st);

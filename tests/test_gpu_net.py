@@ -387,6 +387,22 @@ def test_hp_tolerance_holds_for_other_weight_draws(seed, gain):
     assert err <= TOL_HP and d.max() <= 1 and np.mean(d == 0) >= 0.99
 
 
+@pytest.mark.parametrize("lo_exp", [9, 12, 16])
+def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir, lo_exp):
+    """The trunk's lo half travels as e4m3(lo * 2^lo_exp) planes (conv_trunk_f16 conv5; S2SR_LO_EXP, default 12).  e4m3's own
+    exponent covers the range, so the choice of scale only moves where very small / very large |x| lose bits: the HP
+    tolerance holds for 2^9 .. 2^16, and the 8-wave path (fp16 lo, S2SR_TRUNK=0) stays the tighter reference."""
+    g = np.load(golden_dir / "g4_full_nets.npz")
+    monkeypatch.setenv("S2SR_LO_EXP", str(lo_exp))
+    y = engine(23, native.PREC_F16_HP).forward_f32(g["x"])
+    err = np.abs(y - g["y_b23"]).max()
+    monkeypatch.setenv("S2SR_TRUNK", "0")
+    y16 = engine(23, native.PREC_F16_HP).forward_f32(g["x"])
+    err16 = np.abs(y16 - g["y_b23"]).max()
+    print(f"lo as e4m3 * 2^{lo_exp}: max-abs err {err:.3e}; fp16 lo (8-wave path) {err16:.3e}")
+    assert err <= TOL_HP and err16 <= TOL_HP and err16 <= err * 1.5
+
+
 def test_subpixel_and_upsample_on_load_forms_agree(monkeypatch):
     """The up-convs run in sub-pixel form (2x2 taps on the source image); S2SR_NO_SUBPIXEL=1 keeps the
     3x3-on-upsampled loader form.  Both must match the oracle, and each other to fp32-rounding level."""

@@ -50,8 +50,8 @@ except Exception:
 summary = {"_meta": {"group": IMGS, "git_rev": rev, "tool": "tools/prof_r02.sh",
                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on tools/quick_bench.py --batch 16 --group 16; "
                              "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B); counter units KiB"}}
-FAM = {"hp": {"rdb_conv1-4": ("conv_trunk_f16<1, 8, 3, 0", 18874368), "rdb_conv5": ("conv_trunk_f16<2, 4, 4, 1", 50331648),
-              "rdb_conv5_rrdb": ("conv_trunk_f16<2, 4, 4, 2", 67108864)},
+FAM = {"hp": {"rdb_conv1-4": ("conv_trunk_f16<1, 8, 3, 0", 18874368), "rdb_conv5": ("conv_trunk_f16<2, 4, 4, 1", 41943040),
+              "rdb_conv5_rrdb": ("conv_trunk_f16<2, 4, 4, 2", 54525952)},
        "fp8": {"rdb_conv1-4": ("conv_trunk_f8<1, 4, 6, 0", 9437184), "rdb_conv5": ("conv_trunk_f8<2, 4, 4, 1", 33554432),
                "rdb_conv5_rrdb": ("conv_trunk_f8<2, 4, 4, 2", 41943040)}}
 for mode, fams in FAM.items():
