@@ -1046,6 +1046,7 @@ static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* ds
                         *d16++ = (co < cout && ci < cin) ? (f16)w[((size_t)co * cin + ci) * taps + t] : (f16)0.f;
                     }
     uint8_t* d = (uint8_t*)d16;
+    static const bool diag_no_wlo = [] { const char* e = getenv("S2SR_DIAG_NO_WLO"); return e && atoi(e) != 0; }();   // numerics diagnostic
     for (int part = 0; part < 2; ++part)                                // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
         for (int pl = 0; pl < 2; ++pl)
             for (int t = 0; t < taps; ++t)
@@ -1058,7 +1059,7 @@ static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* ds
                                 if (co < cout && ci < cin) {
                                     const float x = w[((size_t)co * cin + ci) * taps + t];
                                     const float hi = (float)(f16)x;
-                                    v = part == 0 ? hi : (x - hi) * 2048.0f;
+                                    v = part == 0 ? hi : (diag_no_wlo ? 0.0f : (x - hi) * 2048.0f);
                                 }
                                 *d++ = f32_to_e4m3(v);
                             }
