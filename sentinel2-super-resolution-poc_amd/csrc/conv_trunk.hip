@@ -27,7 +27,16 @@
 //   * the slab swizzle is keyed on the COLUMN's bit 3 (not the pixel index's): conflict-free for
 //     ds_read_b128 all the same, and it makes every fragment address "per-lane base + immediate".
 //   * the first MFMA of an accumulator in a patch takes C = 0, the bias is added in the epilogue
-//     (no 128 v_accvgpr_write per patch).
+//     (no 128 v_accvgpr_write per patch) -- or, conv1-4 forms, takes the bias as its C operand.
+//   * the trunk is carried as a pair: fp16 hi (the MFMA operand of the next RDB) + a lo half that conv5 reads and
+//     writes as e4m3(lo * 2^lo_exp) planes of 32 channels -- 4 significant bits of lo keep the net inside 3e-4 of the
+//     fp32 reference at half the lo traffic.
+//   * what binds these kernels is the memory side and the clock the socket power leaves it (profiles/
+//     r02_trunk_anatomy.txt section 8: with the MFMAs compiled out, -DS2SR_DIAG_NOMFMA=1, 70-86 % of the time remains;
+//     per clock the shipped kernels are at 0.8-1.0 of that rate).  Bytes and instructions (joules) are what count.
+//
+// conv_trunk_f8 (second half of the file): the same schedule on e4m3 planes of 32 channels with the K = 64
+// block-scaled MFMA; its conv1-4 form runs with a fifth, load-only wave (PROD).
 #include <math.h>
 #include <stdlib.h>
 
