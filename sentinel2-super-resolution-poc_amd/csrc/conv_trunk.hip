@@ -789,7 +789,8 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
     if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
     int sa[CT];                                                  // E8M0 weight scale of my cout row, per cout tile
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) sa[ct] = p.wscale[ct * 32 + pcol];
+    for (int ct = 0; ct < CT; ++ct) sa[ct] = p.wscale[ct * 32 + pcol] + (kTrunk ? 0 : p.g_exp);   // conv1-4: the accumulator comes out in the
+                                                                                                  // scale of the planes it is stored in (E8M0 exponents add)
 
     // ---- per-lane global offsets of my DMA pieces.  Slab: instruction sl of a pair-step moves piece wave + 4*(sl % PWP) of
     // plane sl / PWP -- which plane is a compile-time property of sl, so the loop carries no selects.
@@ -956,7 +957,7 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = p.bias[ct * 32 + 8 * g + 4 * hh + i];
+                for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = __builtin_ldexpf(p.bias[ct * 32 + 8 * g + 4 * hh + i], p.g_exp);   // bias in the accumulator's scale
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
     }
@@ -1213,16 +1214,20 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
                     if (EPI == EPI_LRELU) {
-                        // bias already in the accumulator; scale, LeakyReLU and both clamps in 4 instructions per pair:
-                        // x = a*s, t = a*(0.2 s) (v_pk_mul_f32), y = max3(x, t, -448), y = min(y, 448)
+                        // bias and the plane scale 2^g_exp are already in the accumulator (C operand, scale_a): LeakyReLU and both
+                        // clamps in 2.5 instructions per value: t = 0.2 a (v_pk_mul_f32), m = max(a, t) (asm: the builtin max
+                        // would first canonicalise the accumulator, a second v_max per value), y = med3(m, -448, 448)
                         float y[4];
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
                             f32x2 a;
                             a[0] = acc[ct][np][4 * g + 2 * h2]; a[1] = acc[ct][np][4 * g + 2 * h2 + 1];
-                            const f32x2 x = a * oscale, t = a * (0.2f * oscale);
-                            y[2 * h2] = fminf(__builtin_fmaxf(__builtin_fmaxf(x[0], t[0]), -448.0f), 448.0f);
-                            y[2 * h2 + 1] = fminf(__builtin_fmaxf(__builtin_fmaxf(x[1], t[1]), -448.0f), 448.0f);
+                            const f32x2 t = a * 0.2f;
+                            float m0, m1;
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m0) : "v"(a[0]), "v"(t[0]));
+                            asm("v_max_f32 %0, %1, %2" : "=v"(m1) : "v"(a[1]), "v"(t[1]));
+                            y[2 * h2] = __builtin_amdgcn_fmed3f(m0, -448.0f, 448.0f);
+                            y[2 * h2 + 1] = __builtin_amdgcn_fmed3f(m1, -448.0f, 448.0f);
                         }
                         int w = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
                         w = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], w, true);
