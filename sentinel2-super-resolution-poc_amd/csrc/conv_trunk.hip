@@ -357,12 +357,29 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     // bytes of its pixel (half-wave 0: channels 0-15 of the plane, half-wave 1: 16-31) and two v_permlane32_swap hand each
     // lane the four dwords that match its accumulator registers -- the store path of the fp8 kernel run backwards.
     f32x4 lo_old[kTrunk ? CT : 1][kTrunk ? NP : 1];
+    // rdb3: the RRDB's input (fp16 hi blocks + e4m3 lo plane) per output row, double-buffered: row 0 is requested with the
+    // lo prefetch, row np + 1 while row np is worked on (a wait on fresh loads would also wait for every DMA issued
+    // before them, and four serial round trips per patch were 15 % of this kernel)
+    constexpr bool kRR = (EPI == EPI_RDB5_RRDB);
+    u32x2 rhi[kRR ? 2 : 1][kRR ? CT : 1][4];
+    f32x4 rlo[kRR ? 2 : 1][kRR ? CT : 1];
+    auto load_skip = [&](int buf, size_t sn, size_t ln, size_t opix) __attribute__((always_inline)) {   // CT * 5 loads
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                rhi[kRR ? buf : 0][kRR ? ct : 0][g] = asm_load8(p.xh_skip + sn + (size_t)(ct * 2 + (g >> 1)) * oblk + opix * 32 + (g & 1) * 16 + hh * 8);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            rlo[kRR ? buf : 0][kRR ? ct : 0] = asm_load16(p.lo_skip + ln + (size_t)ct * oblk + opix * 32 + hh * 16);
+    };
     auto prefetch_lo = [&](int it) __attribute__((always_inline)) {
         const int tile = it * nwg + slot_in_round;
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
         const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
         const size_t ln = (size_t)n * 2 * oblk;
+        if (kRR) load_skip(0, (size_t)n * p.xh_img, ln, (size_t)(ty * G::TH + wave * NP + 1) * p.Wp + (tx * G::TW + pcol + 1));
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const size_t opix = (size_t)(ty * G::TH + wave * NP + np + 1) * p.Wp + (tx * G::TW + pcol + 1);
@@ -483,8 +500,6 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t ln = (size_t)n * 2 * oblk;   // image offset inside the e4m3 lo tensors, bytes
-        u32x2 rhi[EPI == EPI_RDB5_RRDB ? CT : 1][4];   // RRDB skip: fp16 hi ...
-        f32x4 rlo[EPI == EPI_RDB5_RRDB ? CT : 1];      // ... + e4m3 lo (16 bytes per lane, see lo_old)
         const float lo_dec = __builtin_ldexpf(1.0f, -p.lo_exp), lo_enc = __builtin_ldexpf(1.0f, p.lo_exp);   // e4m3 lo planes hold lo * 2^lo_exp
         // the four dwords of a lane's channel groups out of the 16 bytes it fetched (q[g] = channels 8g+4hh.. of the plane)
         auto unswap = [&](const f32x4& o, uint32_t (&q)[4]) __attribute__((always_inline)) {
@@ -506,24 +521,21 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         }
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
-            if (EPI == EPI_RDB5_RRDB) {
+            if (kRR) {
+                // row np's skip was requested one row ago (row 0: with the lo prefetch, already waited for above); the request
+                // of row np + 1 and the stores of row np - 1 are younger and stay in flight
+                constexpr int LR = CT * 5, SR = CT * 3;        // loads / stores per row and wave
+                if (np + 1 < NP) load_skip((np + 1) & 1, sn, ln, opix[np + 1]);
+                if (np > 0) {
+                    if (np + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR + SR) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR) : "memory");
+                }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const size_t off = (size_t)(ct * 2 + (g >> 1)) * oblk + opix[np] * 32 + (g & 1) * 16 + hh * 8;
-                        rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g] = asm_load8(p.xh_skip + sn + off);
-                    }
+                    for (int g = 0; g < 4; ++g) asm_land(rhi[kRR ? np & 1 : 0][kRR ? ct : 0][g]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    rlo[EPI == EPI_RDB5_RRDB ? ct : 0] = asm_load16(p.lo_skip + ln + (size_t)ct * oblk + opix[np] * 32 + hh * 16);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) asm_land(rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g]);
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) asm_land(rlo[EPI == EPI_RDB5_RRDB ? ct : 0]);
+                for (int ct = 0; ct < CT; ++ct) asm_land(rlo[kRR ? np & 1 : 0][kRR ? ct : 0]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -531,7 +543,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                 u32x2 hpk[4];
                 uint32_t lq8[4], loq[4], rlq[4];
                 if (kTrunk) unswap(lo_old[kTrunk ? ct : 0][kTrunk ? np : 0], loq);
-                if (EPI == EPI_RDB5_RRDB) unswap(rlo[EPI == EPI_RDB5_RRDB ? ct : 0], rlq);
+                if (kRR) unswap(rlo[kRR ? np & 1 : 0][kRR ? ct : 0], rlq);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 v;
@@ -560,7 +572,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         u32x2 rh16;
                         if (EPI == EPI_RDB5_RRDB) {
                             rl01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rlq[g], false); rl23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)rlq[g], true);
-                            rh16 = rhi[EPI == EPI_RDB5_RRDB ? ct : 0][g];
+                            rh16 = rhi[kRR ? np & 1 : 0][kRR ? ct : 0][g];
                         }
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
