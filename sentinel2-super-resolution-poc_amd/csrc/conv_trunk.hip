@@ -53,6 +53,11 @@
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
+#ifndef S2SR_F16_PULL
+#define S2SR_F16_PULL 0         // conv_trunk_f16 conv5: 1 = the DMA quota of a patch's first stage is issued inside the previous patch's epilogue
+                                // (the slot is free by then), so the ring does not run down while the wave converts and stores.  Measured
+                                // (tools/ab_macro.sh, one box, A/B/A/B): conv5 232.8 / 232.1 against 229.9 / 231.2 us -- nothing; off.
+#endif
 #ifndef S2SR_DIAG_NOLO
 #define S2SR_DIAG_NOLO 0        // numerics diagnostic (tools/nolo_probe.sh): the fp16 trunk carried WITHOUT its lo half.  Measured: max-abs
                                 // 2.2e-3 .. 3.4e-3 instead of 7e-5 .. 1.8e-4: the pair is what the 1e-3 costs (its lo half needs only e4m3, see the epilogue)
@@ -302,6 +307,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
     // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
     constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
+    constexpr bool kPull = kTrunk && (S2SR_F16_PULL != 0) && G::PFW == 0;
     f32x16 bacc[kBiasC ? CT : 1];
     if (kBiasC) {
 #pragma unroll
@@ -398,7 +404,9 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         const uint32_t dma_off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
         const char* sb = smem + cur_off;
         const char* sn = smem + next_off;
-        cursor_next();                                            // the stage R-1 ahead: its DMA rides on this stage
+        // conv5 (kPull): the first stage of every patch but the first finds its DMA quota already issued by the epilogue before it
+        const bool pulled = kPull && FIRST && !first_patch;
+        if (!pulled) cursor_next();                               // the stage R-1 ahead: its DMA rides on this stage
         if (G::PFW > 0) pf_next();                                // and S2SR_L2PF stages beyond it: L2 prefetch
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
-                if ((sl * (G::T - 3)) / G::PW == t) dma_piece(sl, dma_off);
+                if ((sl * (G::T - 3)) / G::PW == t && !pulled) dma_piece(sl, dma_off);
 #pragma unroll
             for (int k = 0; k < G::PFW; ++k)
                 if (((2 * k + 1) * (G::T - 3)) / (2 * G::PFW) == t) pf_piece(k);
@@ -519,6 +527,15 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     asm_land(lo_old[ct][np]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // kPull: the next patch's first stage would refill the slot of the stage just finished; do it now (that stage then
+        // issues nothing), so the ring stays full while this wave converts and stores.  Behind the row waits of rdb3 (below).
+        auto pull_burst = [&]() __attribute__((always_inline)) {
+            const uint32_t off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
+            cursor_next();
+#pragma unroll
+            for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, off);
+        };
+        if (kPull && !kRR) pull_burst();
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             if (kRR) {
@@ -528,7 +545,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                 if (np + 1 < NP) load_skip((np + 1) & 1, sn, ln, opix[np + 1]);
                 if (np > 0) {
                     if (np + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR + SR) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR + (kPull ? G::PW : 0)) : "memory");   // + the pulled DMA quota (below)
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -537,6 +554,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) asm_land(rlo[kRR ? np & 1 : 0][kRR ? ct : 0]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kPull && np == NP - 2) pull_burst();          // every skip request is out: nothing later waits behind these
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
