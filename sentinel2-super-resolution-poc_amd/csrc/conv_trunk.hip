@@ -1443,15 +1443,15 @@ void pack_conv_weights_f8(const float* w, int cin, int cout, void* dst_host, int
 
 hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_t st) {
     if (ct == 1 && epi == EPI_LRELU) {
-        static const bool w8 = [] { const char* e = getenv("S2SR_FP8_W8"); return e && atoi(e) != 0; }();
-        // S2SR_FP8_WSTREAM: 0 (default) conv1-3 keep their weights resident in LDS (<= 4 planes incl. a phantom, next to the 6-slot
+        // kernel forms, all bit-identical in their results (tests/test_gpu_net.py); p.f8_form comes from the environment at s2sr_create:
+        // weights (S2SR_FP8_WSTREAM): 0 (default) conv1-3 keep theirs resident in LDS (<= 4 planes incl. a phantom, next to the 6-slot
         // slab ring), conv4 streams them (6 planes would cost two slab slots); 1 all stream; 2 all resident (conv4 on a 4-slot ring).
         // Measured on one box, conv1-4 per 5 steps: 108.7 / 109.8 / 111.9 ms -- +1 %, nothing like the -18 % a "no weight DMA"
         // diagnostic suggested (that one read zeros as weights, and an MFMA fed zeros draws less power: the chip clocked higher).
-        static const int stream_w = [] { const char* e = getenv("S2SR_FP8_WSTREAM"); return e ? atoi(e) : 0; }();
-        // the loader-wave form (conv_trunk_f8 PROD) is the default: 77.5 against 79.8 us per conv1-4 launch of 32 tiles on one box,
+        // The loader-wave form (conv_trunk_f8 PROD) is the default: 77.5 against 79.8 us per conv1-4 launch of 32 tiles on one box,
         // A/B/A/B (+3 %; the no-MFMA floor of either form is 58 us).  S2SR_FP8_LOADER=0 selects the four-wave forms below.
-        static const bool loader = [] { const char* e = getenv("S2SR_FP8_LOADER"); return !e || atoi(e) != 0; }();
+        const bool w8 = (p.f8_form & 8) != 0, loader = (p.f8_form & 1) == 0;
+        const int stream_w = (p.f8_form >> 1) & 3;
         if (w8) return launch_trunk8_t<1, 2, 6, EPI_LRELU, 8>(p, st);
         if (loader) return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4, 1>(p, st) : launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 0, 1>(p, st);
         if (stream_w == 1 || (stream_w == 0 && p.nstage > 4)) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);

@@ -119,6 +119,7 @@ struct s2sr_handle {
     float* d_calib = nullptr;     // fp8 calibration: [0] max |x| of the trunk, [1] max |x_k| of the growth planes (device)
     bool fp8_hp_tail = false;     // S2SR_PREC_FP8: the six head / tail convs in plain fp16 (their ~2e-3 is below the trunk's e4m3
                                   // error) unless S2SR_FP8_TAIL=hp asks for the split-operand forms
+    int fp8_form = 0;             // ConvParams::f8_form (S2SR_FP8_LOADER / S2SR_FP8_WSTREAM / S2SR_FP8_W8)
     int lo_exp = 12;              // fp16 modes, one-wave-per-SIMD trunk: the trunk's lo half as e4m3(lo * 2^lo_exp): exact to 4 bits for
                                   // |x| < 2^(20 - lo_exp) = 256, clamped beyond (S2SR_LO_EXP)
     int fp8_x_exp = 3, fp8_g_exp = 5;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP); calibrated
@@ -389,7 +390,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
                     p.src = w.D8[cur]; p.src_img = 6 * w.blk1;
                     p.wpack = cw.d_wpack; p.bias = cw.d_bias; p.wscale = cw.d_wscale;
                     p.nstage = cw.nstage; p.seg_len = cw.seg_len; p.trash = h->d_trash;
-                    p.x_exp = xe; p.g_exp = ge; p.xh_img = 4 * w.blk1;
+                    p.x_exp = xe; p.g_exp = ge; p.xh_img = 4 * w.blk1; p.f8_form = h->fp8_form;
                     int epi = EPI_LRELU;
                     double bytes = px * (32.0 * cw.seg_len);                     // algorithmic: every input byte once
                     if (k < 5) {
@@ -647,6 +648,9 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
+    if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
+    if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
+    if (const char* g = getenv("S2SR_FP8_W8")) h->fp8_form |= atoi(g) != 0 ? 8 : 0;
     if (const char* g = getenv("S2SR_LO_EXP")) {
         const int v = atoi(g);
         if (v >= 6 && v <= 18) h->lo_exp = v;

@@ -83,6 +83,8 @@ struct ConvParams {
     uint64_t xh_img;         // bytes between images of the three
     const int32_t* wscale;   // [64] E8M0 bytes 127 - k_co of the per-output-channel weight scales 2^k_co
     int32_t x_exp, g_exp;    // activation scales: x planes hold e4m3(x * 2^x_exp), growth planes e4m3(x_k * 2^g_exp)
+    int32_t f8_form;         // conv_trunk_f8 conv1-4 kernel form (diagnostics): bit 0 no loader wave, bits 1-2 weight placement (0 default, 1 all
+                             // streamed, 2 all resident), bit 3 two waves per SIMD -- from S2SR_FP8_LOADER / _WSTREAM / _W8 at s2sr_create
     int32_t lo_exp;          // conv_trunk_f16 conv5: the trunk's lo half is stored as e4m3(lo * 2^lo_exp) planes (xh_in, T, lo_skip)
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup

@@ -615,6 +615,21 @@ def test_fp8_mode_full_tile_and_batch_properties():
         assert a.shape == (4 * H, 4 * W, 3) and np.isfinite(a).all() and np.abs(a - b).max() <= TOL_FP8_23, (H, W)
 
 
+@pytest.mark.parametrize("env", [{"S2SR_FP8_LOADER": "0"}, {"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "1"},
+                                 {"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "2"}, {"S2SR_FP8_W8": "1"}])
+def test_fp8_conv14_kernel_forms_agree_bit_for_bit(monkeypatch, env):
+    """The fp8 conv1-4 kernel comes in several forms (a fifth load-only wave or not, weights streamed or resident in LDS,
+    one or two waves per SIMD).  They accumulate the same products in the same order, so whichever form the environment
+    selects must give the same bytes as the default."""
+    from s2sr.synth import synthetic_tiles
+    tiles = synthetic_tiles(3, 96, seed=5)
+    y0 = engine(6, native.PREC_FP8).forward_batch_u8(tiles)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    y1 = engine(6, native.PREC_FP8).forward_batch_u8(tiles)
+    assert np.array_equal(y0, y1), env
+
+
 def test_fp8_calibration_sets_scales_from_data(golden_dir):
     """s2sr_calibrate_fp8: activation scales of the fp8 trunk from the largest |x| / |x_k| seen over all RDBs on
     representative tiles.  On the synthetic set it must land near the shipped defaults, keep the
