@@ -320,7 +320,7 @@ def main():
                                      "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 8e-5..1.9e-4 vs the fp32 reference"
                                      if a.precision == "hp" else
                                      "the 345 RDB convs on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, "
-                                     "per-tensor-kind activation scales, fp32 accumulate, fp16 trunk); head/tail convs as in hp: measured max-abs "
+                                     "per-tensor-kind activation scales, fp32 accumulate, fp16 trunk); head/tail convs in plain fp16 (S2SR_FP8_TAIL=hp for the split forms): measured max-abs "
                                      "4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference, u8 within 1 LSB (93-95 % of bytes identical) -- NOT inside the 1e-3 tolerance"
                                      if a.precision == "fp8" else
                                      "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference")},

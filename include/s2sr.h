@@ -41,7 +41,8 @@ extern "C" {
                             * fp32-class head/tail, ~1e-4 of the fp32 reference at ~1.2x the time            */
 
 #define S2SR_PREC_FP8 2    /* the 345 RDB convs on e4m3 operands (block-scaled fp8 MFMA, K = 64; per-output-channel weight
-                            * scales, per-tensor-kind activation scales, fp16 trunk); head / tail convs as in F16_HP.
+                            * scales, per-tensor-kind activation scales, fp16 trunk); the six head / tail convs in PLAIN fp16 (as S2SR_PREC_F16;
+                            * their ~2e-3 is below the trunk's e4m3 error) unless S2SR_FP8_TAIL=hp selects the split-operand forms.
                             * BASELINE.json configs[4] (the /api/sr variant).  NOT within the 1e-3 tolerance: e4m3 keeps
                             * 3 mantissa bits; measured max-abs in tests/test_gpu_net.py (test_fp8_mode_*)             */
 
@@ -211,6 +212,47 @@ int  s2sr_debug_pack_f8(const float* w, int32_t cin, int32_t cout, uint8_t* out,
 int  s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int32_t H, int32_t W,
                      const float* weight, const float* bias, int32_t Cout, int32_t upsample,
                      int32_t act, float* y);
+
+/* test hook: what s2sr_create read from the environment (every kernel-form / scale switch is fixed at creation), so a
+ * test that sets S2SR_* can assert the switch took on the handle it then creates. */
+typedef struct s2sr_debug_config {
+    int32_t precision;      /* S2SR_PREC_* */
+    int32_t group;          /* cfg.group as given (0 = default) */
+    int32_t trunk_w4;       /* 1: RDB convs on the one-wave-per-SIMD kernels (conv_trunk.hip); 0: 8-wave kernel (S2SR_TRUNK=0) */
+    int32_t lo_exp;         /* trunk lo half as e4m3(lo * 2^lo_exp) (S2SR_LO_EXP) */
+    int32_t fp8_form;       /* conv_trunk_f8 conv1-4 form bits: 1 no loader wave, 2/4 weight placement, 8 two waves per SIMD */
+    int32_t fp8_x_exp, fp8_g_exp;   /* fp8 trunk activation scales (S2SR_FP8_XEXP / _GEXP or s2sr_calibrate_fp8) */
+    int32_t fp8_hp_tail;    /* S2SR_FP8_TAIL=hp */
+    int32_t graphs_on;      /* S2SR_GRAPH */
+    int32_t trunk_wino;     /* 1: fp16 RDB conv1-4 in the row-Winograd F(2,3) form (S2SR_WINO) */
+    int32_t reserved[6];
+} s2sr_debug_config;
+int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
+
+/* test hook: ONE RDB-shaped conv through the TRUNK kernels (conv_trunk.hip: conv_trunk_f16 / conv_trunk_f8), host tensors in
+ * NCHW fp32 -- the per-layer parity check of the kernels that carry 84 % of a step (s2sr_debug_conv goes through conv3x3.hip).
+ *   kind 0: fp16 conv1-4 form   y = lrelu(conv(x) + b)                        Cin in {64,96,128,160}, Cout 32, y = the fp16 plane written
+ *   kind 1: fp16 conv5 form     y = 0.2*(conv(x) + b) + (x[:, :64] + lo)     Cin 192, Cout 64, y = hi + lo of the (fp16, e4m3) pair written
+ *   kind 2: fp16 conv5 of rdb3  y = 0.2*(kind 1) + skip
+ *   kind 3: fp8 conv1-4 form    y = e4m3(lrelu(conv + b) * 2^g_exp) / 2^g_exp  (x planes at 2^x_exp, growth planes at 2^g_exp)
+ *   kind 4: fp8 conv5 form      y = fp16(0.2*(conv + b) + x[:, :64]); y_aux = its e4m3(* 2^x_exp) image
+ *   kind 5: fp8 conv5 of rdb3   y = fp16(0.2*(kind 4 value) + skip)
+ * x is rounded to the operand format on the way in (fp16, or e4m3 at the handle's scales), so callers pass representable
+ * values; `lo` ([N,64,H,W], kinds 1-2, may be NULL) is stored as e4m3(lo * 2^lo_exp); `skip` ([N,64,H,W]) as the
+ * (fp16 hi, e4m3 lo) pair (kind 2) or fp16 (kind 5).  form: kind 0: 0 auto, 1 = 16x32 patches, 2 = 32x32 patches,
+ * 3 = row-Winograd F(2,3); kind 3: the fp8_form bits. */
+typedef struct s2sr_debug_trunk_args {
+    int32_t kind, form;
+    int32_t N, Cin, H, W;
+    const float* x;
+    const float* weight;    /* [Cout,Cin,3,3] */
+    const float* bias;      /* [Cout] */
+    const float* lo;
+    const float* skip;
+    float* y;               /* [N,Cout,H,W] */
+    float* y_aux;           /* kinds 4-5: [N,64,H,W], may be NULL */
+} s2sr_debug_trunk_args;
+int  s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a);
 
 /* diagnostic: time one RDB-shaped conv (cin in {64,96,128,160,192}; cout 32 -> conv1..4 form,
  * cout 64 -> conv5 form) over N images of HxW, `iters` launches; avg_us = mean launch time from

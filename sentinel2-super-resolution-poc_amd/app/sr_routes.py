@@ -273,6 +273,9 @@ def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optio
         if "image" not in fields or fields["image"][0] is None:
             raise HTTPException(status_code=422, detail="field `image` (file) is required")
         filename, content = fields["image"]
+        safe_name = Path(filename).name                                       # never trust a client path
+        if safe_name in ("", ".", ".."):
+            raise HTTPException(status_code=422, detail="field `image` needs a file name")
         if len(content) > max_upload_bytes:
             raise HTTPException(status_code=413,
                                 detail=f"Upload exceeds maximum allowed size of {max_upload_bytes // (1024 * 1024)} MB")
@@ -287,7 +290,7 @@ def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optio
             upload_dir = data_dir / "uploads" / job_id
             output_dir.mkdir(parents=True, exist_ok=True)
             upload_dir.mkdir(parents=True, exist_ok=True)
-            uploaded_path = upload_dir / Path(filename).name       # never trust a client path
+            uploaded_path = upload_dir / safe_name
             uploaded_path.write_bytes(content)
             _set(job_id, status="queued", message="Enhancement queued", input_file=str(uploaded_path),
                  output_dir=str(output_dir), model=model, created_at=datetime.now().isoformat())
@@ -304,6 +307,9 @@ def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optio
         except HTTPException:
             raise
         except Exception as e:                                               # noqa: BLE001 -- main.py:624-626
+            with lock:                       # no status-less placeholder may stay in the table GET /api/sr serves
+                if "job_id" in locals() and not sr_jobs.get(job_id, {}).get("status"):
+                    sr_jobs.pop(job_id, None)
             raise HTTPException(status_code=500, detail=str(e))
 
     return app

@@ -484,6 +484,13 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         // the MFMA results must have left the matrix pipe before the VALU reads them; hipcc does not know these
         // asm statements are MFMAs, so the wait states are spelled out (16-pass MFMA: 18 needed)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // ... and tied to the data: every accumulator passes through an empty "+a" statement BEHIND the nops, so no read of
+        // it (hipcc hoisted 16-17 v_accvgpr_read above the nops before this; tools/check_asm_loads.py now counts the wait
+        // states between an inline MFMA and the first non-MFMA read of its destination) can be scheduled in front of them
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int np = 0; np < NP; ++np) asm_land(acc[ct][np]);
         const int tile = it * nwg + slot_in_round;
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
@@ -1175,6 +1182,10 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
 
     auto epilogue = [&](int it) __attribute__((always_inline)) {
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // MFMA results -> VALU reads (see conv_trunk_f16)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int np = 0; np < NP; ++np) asm_land(acc[ct][np]);   // tie the wait to the data
         const int tile = it * nwg + slot_in_round;
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
@@ -1383,8 +1394,10 @@ hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
 
 // ct = 1: conv1..4 (EPI_LRELU); ct = 2: conv5 (EPI_RDB5 / EPI_RDB5_RRDB).  Returns hipErrorNotSupported for
 // anything else.
-hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace) {
+hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace, int force_form) {
     if (ct == 1 && epi == EPI_LRELU) {
+        if (force_form == 1) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);      // per-layer parity hook: name the patch form
+        if (force_form == 2) return launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
         // 32x32 patches (8 rows per wave, 3-deep ring) unless that leaves most CUs without a patch (single tiles):
         // then 16x32 patches (4 rows per wave, 5-deep ring) spread the image over twice as many workgroups.  Both
         // forms accumulate in the same order, so the result does not depend on the choice.

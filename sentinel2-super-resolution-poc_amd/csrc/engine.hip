@@ -124,6 +124,8 @@ struct s2sr_handle {
                                   // |x| < 2^(20 - lo_exp) = 256, clamped beyond (S2SR_LO_EXP)
     int fp8_x_exp = 3, fp8_g_exp = 5;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP); calibrated
                                         // on the synthetic set: profiles/r02_fp8_scale_sweep.txt (|x| up to 56, |x_k| up to 14 before clipping)
+    int fp8_x_exp0 = 3, fp8_g_exp0 = 5; // ... as s2sr_create left them: every weight load starts from these again (a calibration belongs to the weights it saw)
+    bool trunk_wino = false;      // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     std::vector<GraphEntry> graphs;
@@ -657,6 +659,8 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     }
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
+    h->fp8_x_exp0 = h->fp8_x_exp; h->fp8_g_exp0 = h->fp8_g_exp;
+    if (const char* g = getenv("S2SR_WINO")) h->trunk_wino = atoi(g) != 0;
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
@@ -704,6 +708,7 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
     drop_graphs(h);
     free_weights(h);
     h->has_weights = false;
+    h->fp8_x_exp = h->fp8_x_exp0; h->fp8_g_exp = h->fp8_g_exp0;     // exponents calibrated for the previous weights do not carry over
     const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
     const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || (fp8 && h->fp8_hp_tail);
     const size_t nconv = specs.size();
@@ -1310,27 +1315,49 @@ int s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t 
     if ((rc = ensure_scratch(h, 1, ob))) return rc;
     float* d_c = nullptr;
     HIPCHK(h, hipMalloc((void**)&d_c, 2 * sizeof(float)));
-    HIPCHK(h, hipMemsetAsync(d_c, 0, 2 * sizeof(float), h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
     const int old_x = h->fp8_x_exp, old_g = h->fp8_g_exp, old_prof = h->prof;
     const bool old_graphs = h->graphs_on;
-    h->fp8_x_exp = 0; h->fp8_g_exp = 2;        // trunk up to 448, growth up to 112: measure without clipping
-    h->graphs_on = false; h->prof = 0;
-    h->d_calib = d_c;
-    rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0], nullptr, B, th, tw, (uint8_t*)h->d_scratch[1], nullptr);
-    h->d_calib = nullptr;
-    h->graphs_on = old_graphs; h->prof = old_prof;
     float m[2] = {0.f, 0.f};
-    hipError_t e = hipMemcpyAsync(m, d_c, sizeof m, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipError_t e = hipSuccess;
+    // The measuring pass itself stores e4m3 planes: with scales 2^mx / 2^mg it sees values up to 448 / 2^mx (trunk) and
+    // 448 / 2^mg (growth) and clips beyond.  Start wide (trunk up to 448, growth up to 112); a maximum that reaches the
+    // pass's own ceiling means "at least this much": measure again 8x wider (twice at most, then report it).
+    int mx = 0, mg = 2;
+    bool clipped = false;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        hipError_t e0 = hipMemsetAsync(d_c, 0, 2 * sizeof(float), h->stream);
+        if (e0 != hipSuccess) { hipFree(d_c); return fail(h, S2SR_E_HIP, "calibration memset failed"); }
+        h->fp8_x_exp = mx; h->fp8_g_exp = mg;
+        h->graphs_on = false; h->prof = 0;
+        h->d_calib = d_c;
+        rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0], nullptr, B, th, tw, (uint8_t*)h->d_scratch[1], nullptr);
+        h->d_calib = nullptr;
+        h->graphs_on = old_graphs; h->prof = old_prof;
+        e = hipMemcpyAsync(m, d_c, sizeof m, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (rc || e != hipSuccess) break;
+        const bool cx = m[0] >= 0.98f * ldexpf(448.0f, -mx), cg = m[1] >= 0.98f * ldexpf(448.0f, -mg);
+        clipped = cx || cg;
+        if (!clipped || attempt == 2) break;
+        if (cx) mx -= 3;
+        if (cg) mg -= 3;
+    }
     hipFree(d_c);
     if (rc || e != hipSuccess) {
         h->fp8_x_exp = old_x; h->fp8_g_exp = old_g;
         return rc ? rc : fail(h, S2SR_E_HIP, std::string("calibration read-back failed: ") + hipGetErrorString(e));
     }
-    auto pick = [&](float mx, int fallback) {
-        if (!(mx > 0.f)) return fallback;
-        int k = (int)floorf(log2f(448.0f / (mx * headroom)));
+    if (clipped) {
+        h->fp8_x_exp = old_x; h->fp8_g_exp = old_g;
+        char b[200];
+        snprintf(b, sizeof b, "fp8 calibration: activations still reach the measuring pass's ceiling at scales 2^%d / 2^%d (|x| >= %g, |x_k| >= %g)",
+                 mx, mg, m[0], m[1]);
+        return fail(h, S2SR_E_INVALID, b);
+    }
+    auto pick = [&](float vmax, int fallback) {
+        if (!(vmax > 0.f)) return fallback;
+        int k = (int)floorf(log2f(448.0f / (vmax * headroom)));
         return k > 12 ? 12 : (k < -8 ? -8 : k);
     };
     drop_graphs(h);                            // captured launches carry the old exponents
@@ -1391,6 +1418,216 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
+    return S2SR_OK;
+}
+
+int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
+    if (!h || !out) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    memset(out, 0, sizeof *out);
+    out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
+    out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino ? 1 : 0;
+    return S2SR_OK;
+}
+
+namespace {
+float e4m3_to_f32(uint8_t b) {   // OCP e4m3fn: bias 7, subnormals, 0x7f / 0xff = NaN
+    const int e = (b >> 3) & 15, m = b & 7;
+    float v = e == 0 ? ldexpf((float)m, -9) : ldexpf((float)(8 + m), e - 10);
+    if ((b & 0x7f) == 0x7f) v = NAN;
+    return (b & 0x80) ? -v : v;
+}
+typedef _Float16 hf16;
+struct DevBuf {   // frees on scope exit: the hook has many early returns
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+}  // namespace
+
+// One RDB-shaped conv through conv_trunk_f16 / conv_trunk_f8.  Host-side packing and decoding (a test hook: clarity over
+// speed); the weights go through the production device packers (pack.hip).
+int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
+    if (!h || !a || !a->x || !a->weight || !a->bias || !a->y) return S2SR_E_INVALID;
+    const int kind = a->kind, N = a->N, Cin = a->Cin, H = a->H, W = a->W;
+    if (kind < 0 || kind > 5 || N <= 0 || H <= 0 || W <= 0) return S2SR_E_INVALID;
+    const bool f8 = kind >= 3, c5 = (kind % 3) != 0, rr = (kind % 3) == 2;
+    const int Cout = c5 ? 64 : 32;
+    if (c5 ? Cin != 192 : (Cin != 64 && Cin != 96 && Cin != 128 && Cin != 160)) return fail(h, S2SR_E_INVALID, "Cin does not match the RDB form");
+    if (rr && !a->skip) return fail(h, S2SR_E_INVALID, "rdb3 form needs skip");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipStream_t st = h->stream;
+    const int Hp = padded(H), Wp = padded(W);
+    const size_t ppx = (size_t)Hp * Wp, blk = ppx * 32;
+    const size_t px = (size_t)H * W;
+    auto pix = [&](int y, int x) { return (size_t)(y + 1) * Wp + (x + 1); };
+    // ---- weights through the production device packers
+    DevBuf d_w32, d_wp, d_b, d_ws;
+    const size_t wn = (size_t)Cout * Cin * 9;
+    HIPCHK(h, hipMalloc(&d_w32.p, wn * 4));
+    HIPCHK(h, hipMemcpyAsync(d_w32.p, a->weight, wn * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMalloc(&d_wp.p, f8 ? conv_wpack_bytes_f8(Cin, Cout) : conv_wpack_bytes(Cin, Cout)));
+    HIPCHK(h, hipMalloc(&d_b.p, 64 * 4));
+    HIPCHK(h, hipMalloc(&d_ws.p, 64 * 4));
+    float bb[64] = {0};
+    memcpy(bb, a->bias, Cout * sizeof(float));
+    HIPCHK(h, hipMemcpyAsync(d_b.p, bb, sizeof bb, hipMemcpyHostToDevice, st));
+    if (f8) HIPCHK(h, launch_pack_trunk_f8((const float*)d_w32.p, Cin, Cout, d_wp.p, (int32_t*)d_ws.p, st));
+    else if (kind == 0 && a->form == 3) HIPCHK(h, launch_pack_trunk_wino((const float*)d_w32.p, Cin, Cout, d_wp.p, st));
+    else HIPCHK(h, launch_pack_trunk_f16((const float*)d_w32.p, Cin, Cout, d_wp.p, st));
+    // ---- activations: the dense tensor D (12 fp16 blocks per image, or 6 e4m3 planes), packed on the host
+    const int xe = h->fp8_x_exp, ge = h->fp8_g_exp, le = h->lo_exp;
+    const size_t dimg = (f8 ? 6 : 12) * blk;
+    std::vector<char> D((size_t)N * dimg, 0);
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < Cin; ++c)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    const float v = a->x[(((size_t)n * Cin + c) * H + y) * W + x];
+                    if (f8) {
+                        const float sc = ldexpf(v, c < 64 ? xe : ge);
+                        ((uint8_t*)D.data())[(size_t)n * dimg + (size_t)(c >> 5) * blk + pix(y, x) * 32 + (c & 31)] = f32_to_e4m3(sc);
+                    } else {
+                        ((hf16*)(D.data() + (size_t)n * dimg + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15] = (hf16)v;
+                    }
+                }
+    // a 64-channel NCHW tensor as (fp16 hi blocks [4], e4m3(lo * 2^le) planes [2]) or as fp16 only
+    auto split64 = [&](const float* src, std::vector<char>& hi, size_t hi_img, std::vector<char>* lo8, bool hi_is_value) {
+        for (int n = 0; n < N; ++n)
+            for (int c = 0; c < 64; ++c)
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) {
+                        const float v = src ? src[(((size_t)n * 64 + c) * H + y) * W + x] : 0.f;
+                        const hf16 hv = (hf16)v;
+                        if (hi_is_value) ((hf16*)(hi.data() + (size_t)n * hi_img + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15] = hv;
+                        if (lo8) {
+                            const float l = hi_is_value ? v - (float)hv : v;
+                            ((uint8_t*)lo8->data())[(size_t)n * 2 * blk + (size_t)(c >> 5) * blk + pix(y, x) * 32 + (c & 31)] = f32_to_e4m3(ldexpf(l, le));
+                        }
+                    }
+    };
+    DevBuf d_D, d_D2, d_Tin, d_Tout, d_Sk, d_SkLo, d_Xin, d_Xout;
+    HIPCHK(h, hipMalloc(&d_D.p, D.size()));
+    HIPCHK(h, hipMemcpyAsync(d_D.p, D.data(), D.size(), hipMemcpyHostToDevice, st));
+    ConvParams p{};
+    p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
+    p.src = (const char*)d_D.p; p.src_img = dimg; p.wpack = d_wp.p; p.bias = (const float*)d_b.p; p.trash = h->d_trash;
+    const int epi = !c5 ? EPI_LRELU : (rr ? EPI_RDB5_RRDB : EPI_RDB5);
+    std::vector<char> tmp;
+    if (!f8) {
+        p.nstage = Cin / 16; p.seg_len = p.nstage; p.lo_exp = le;
+        if (!c5) {
+            p.dst = (char*)d_D.p + (size_t)(Cin / 16) * blk; p.dst_img = dimg;       // the next growth slot of the same dense tensor
+        } else {
+            HIPCHK(h, hipMalloc(&d_D2.p, D.size()));
+            HIPCHK(h, hipMemsetAsync(d_D2.p, 0, D.size(), st));
+            p.dst = (char*)d_D2.p; p.dst_img = dimg;
+            std::vector<char> lo8((size_t)N * 2 * blk, 0), none;
+            split64(a->lo, none, 0, &lo8, false);
+            HIPCHK(h, hipMalloc(&d_Tin.p, lo8.size()));
+            HIPCHK(h, hipMalloc(&d_Tout.p, lo8.size()));
+            HIPCHK(h, hipMemcpyAsync(d_Tin.p, lo8.data(), lo8.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemsetAsync(d_Tout.p, 0, lo8.size(), st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            p.xh_in = (const char*)d_Tin.p; p.T = (char*)d_Tout.p;
+            if (rr) {
+                std::vector<char> shi((size_t)N * 4 * blk, 0), slo((size_t)N * 2 * blk, 0);
+                split64(a->skip, shi, 4 * blk, &slo, true);
+                HIPCHK(h, hipMalloc(&d_Sk.p, shi.size()));
+                HIPCHK(h, hipMalloc(&d_SkLo.p, slo.size()));
+                HIPCHK(h, hipMemcpyAsync(d_Sk.p, shi.data(), shi.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(h, hipMemcpyAsync(d_SkLo.p, slo.data(), slo.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(h, hipStreamSynchronize(st));
+                p.xh_skip = (const char*)d_Sk.p; p.xh_img = 4 * blk; p.lo_skip = (const char*)d_SkLo.p;
+            }
+        }
+        hipError_t e;
+        if (kind == 0 && a->form == 3) e = launch_conv_trunk_wino(p, st);
+        else e = launch_conv_trunk(p, Cout / 32, epi, st, false, kind == 0 ? a->form : 0);
+        if (e != hipSuccess) return fail(h, S2SR_E_HIP, std::string("launch_conv_trunk: ") + hipGetErrorString(e));
+    } else {
+        p.seg_len = Cin / 32; p.nstage = (p.seg_len + 1) & ~1; p.wscale = (const int32_t*)d_ws.p;
+        p.x_exp = xe; p.g_exp = ge; p.f8_form = kind == 3 ? a->form : 0; p.xh_img = 4 * blk;
+        if (!c5) {
+            p.dst = (char*)d_D.p + (size_t)(Cin / 32) * blk; p.dst_img = dimg;
+        } else {
+            HIPCHK(h, hipMalloc(&d_D2.p, D.size()));
+            HIPCHK(h, hipMemsetAsync(d_D2.p, 0, D.size(), st));
+            p.dst = (char*)d_D2.p; p.dst_img = dimg;
+            std::vector<char> xin((size_t)N * 4 * blk, 0);      // the fp16 trunk = the first 64 of the Cin input channels
+            for (int n = 0; n < N; ++n)
+                for (int c = 0; c < 64; ++c)
+                    for (int y = 0; y < H; ++y)
+                        for (int x = 0; x < W; ++x)
+                            ((hf16*)(xin.data() + (size_t)n * 4 * blk + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15] =
+                                (hf16)a->x[(((size_t)n * Cin + c) * H + y) * W + x];
+            HIPCHK(h, hipMalloc(&d_Xin.p, xin.size()));
+            HIPCHK(h, hipMalloc(&d_Xout.p, xin.size()));
+            HIPCHK(h, hipMemcpyAsync(d_Xin.p, xin.data(), xin.size(), hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemsetAsync(d_Xout.p, 0, xin.size(), st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            p.xh_in = (const char*)d_Xin.p; p.xh_out = (char*)d_Xout.p;
+            if (rr) {
+                std::vector<char> shi((size_t)N * 4 * blk, 0);
+                split64(a->skip, shi, 4 * blk, nullptr, true);
+                HIPCHK(h, hipMalloc(&d_Sk.p, shi.size()));
+                HIPCHK(h, hipMemcpyAsync(d_Sk.p, shi.data(), shi.size(), hipMemcpyHostToDevice, st));
+                HIPCHK(h, hipStreamSynchronize(st));
+                p.xh_skip = (const char*)d_Sk.p;
+            }
+        }
+        const hipError_t e = launch_conv_trunk_f8(p, Cout / 32, epi, st);
+        if (e != hipSuccess) return fail(h, S2SR_E_HIP, std::string("launch_conv_trunk_f8: ") + hipGetErrorString(e));
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+    // ---- read back and decode
+    auto get = [&](const void* d, size_t bytes) -> int {
+        tmp.resize(bytes);
+        HIPCHK(h, hipMemcpy(tmp.data(), d, bytes, hipMemcpyDeviceToHost));
+        return S2SR_OK;
+    };
+    int rc;
+    auto for_out = [&](int C, auto fn) {
+        for (int n = 0; n < N; ++n)
+            for (int c = 0; c < C; ++c)
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) fn(n, c, y, x, (((size_t)n * C + c) * H + y) * W + x);
+    };
+    if (!f8 && !c5) {
+        if ((rc = get(d_D.p, D.size()))) return rc;
+        const size_t ob = (size_t)(Cin / 16) * blk;
+        for_out(32, [&](int n, int c, int y, int x, size_t o) {
+            a->y[o] = (float)((const hf16*)(tmp.data() + (size_t)n * dimg + ob + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15];
+        });
+    } else if (!f8) {
+        if ((rc = get(d_D2.p, D.size()))) return rc;
+        std::vector<char> hi = tmp;
+        if ((rc = get(d_Tout.p, (size_t)N * 2 * blk))) return rc;
+        for_out(64, [&](int n, int c, int y, int x, size_t o) {
+            const float hv = (float)((const hf16*)(hi.data() + (size_t)n * dimg + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15];
+            const uint8_t lb = ((const uint8_t*)tmp.data())[(size_t)n * 2 * blk + (size_t)(c >> 5) * blk + pix(y, x) * 32 + (c & 31)];
+            a->y[o] = hv + ldexpf(e4m3_to_f32(lb), -le);
+        });
+    } else if (!c5) {
+        if ((rc = get(d_D.p, D.size()))) return rc;
+        const size_t ob = (size_t)(Cin / 32) * blk;
+        for_out(32, [&](int n, int c, int y, int x, size_t o) {
+            a->y[o] = ldexpf(e4m3_to_f32(((const uint8_t*)tmp.data())[(size_t)n * dimg + ob + pix(y, x) * 32 + c]), -ge);
+        });
+    } else {
+        if ((rc = get(d_Xout.p, (size_t)N * 4 * blk))) return rc;
+        for_out(64, [&](int n, int c, int y, int x, size_t o) {
+            a->y[o] = (float)((const hf16*)(tmp.data() + (size_t)n * 4 * blk + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15];
+        });
+        if (a->y_aux) {
+            if ((rc = get(d_D2.p, D.size()))) return rc;
+            for_out(64, [&](int n, int c, int y, int x, size_t o) {
+                a->y_aux[o] = ldexpf(e4m3_to_f32(((const uint8_t*)tmp.data())[(size_t)n * dimg + (size_t)(c >> 5) * blk + pix(y, x) * 32 + (c & 31)]), -xe);
+            });
+        }
+    }
+    (void)px;
     return S2SR_OK;
 }
 

@@ -97,7 +97,13 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
 // the RRDB trunk convs as one-wave-per-SIMD workgroups (conv_trunk.hip): ct 1 + EPI_LRELU (conv1..4), ct 2 + EPI_RDB5 /
 // EPI_RDB5_RRDB (conv5).  hipErrorNotSupported = not a trunk form / launch too small: use launch_conv.
-hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace = false);
+// force_form (conv1-4 only; the per-layer parity hook): 0 = by launch size, 1 = 16x32 patches / 5-deep ring, 2 = 32x32 patches / 3-deep ring
+hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace = false, int force_form = 0);
+// fp16 RDB conv1..4 in the row-Winograd F(2,3) form (conv_wino.hip): weights transformed over dy (4 x 3 fragments per 16-channel
+// stage instead of 3 x 3), inputs transformed over 4 consecutive slab rows in registers, 12 MFMAs per 2 output rows instead of 18
+hipError_t launch_conv_trunk_wino(const ConvParams& p, hipStream_t st);
+size_t conv_wpack_bytes_wino(int cin, int cout);
+hipError_t launch_pack_trunk_wino(const float* d_w, int cin, int cout, void* d_out, hipStream_t st);
 // the same convs on e4m3 operands, block-scaled fp8 MFMA (K = 64 = two planes per instruction)
 hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_t st);
 // per-plane weight stages for conv_trunk_f8: [plane][tap][ct][16-B half][cout row 0..31][16 channel bytes] e4m3 of

@@ -40,6 +40,16 @@ class PPParams(C.Structure):
                 ("sat_gain", C.c_float), ("stages", C.c_int32)]
 
 
+class DebugConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("precision", "group", "trunk_w4", "lo_exp", "fp8_form", "fp8_x_exp", "fp8_g_exp",
+                                         "fp8_hp_tail", "graphs_on", "trunk_wino")] + [("reserved", C.c_int32 * 6)]
+
+
+class DebugTrunkArgs(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "form", "N", "Cin", "H", "W")] + \
+               [(n, C.c_void_p) for n in ("x", "weight", "bias", "lo", "skip", "y", "y_aux")]
+
+
 class KStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
@@ -96,6 +106,8 @@ _PROTOS = {
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
+    "s2sr_debug_get_config": (C.c_int, [C.c_void_p, C.POINTER(DebugConfig)]),
+    "s2sr_debug_conv_trunk": (C.c_int, [C.c_void_p, C.POINTER(DebugTrunkArgs)]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -374,6 +386,39 @@ class Engine:
         self._check(self._lib.s2sr_debug_conv(self._h, _ptr(x), N, cin, H, W, _ptr(weight), _ptr(bias), cout,
                                               int(upsample), int(act), _ptr(y)), "s2sr_debug_conv")
         return y
+
+
+TRUNK_F16_CONV14, TRUNK_F16_CONV5, TRUNK_F16_CONV5_RRDB, TRUNK_F8_CONV14, TRUNK_F8_CONV5, TRUNK_F8_CONV5_RRDB = range(6)
+
+
+def _debug_config(self) -> dict:
+    """What s2sr_create read from the environment for this handle (kernel forms, scales)."""
+    c = DebugConfig()
+    self._check(self._lib.s2sr_debug_get_config(self._h, C.byref(c)), "s2sr_debug_get_config")
+    return {n: int(getattr(c, n)) for n, _ in DebugConfig._fields_ if n != "reserved"}
+
+
+def _debug_conv_trunk(self, kind, x, weight, bias, lo=None, skip=None, form=0):
+    """One RDB-shaped conv through conv_trunk_f16 / conv_trunk_f8 (include/s2sr.h: s2sr_debug_conv_trunk).
+    Returns y, or (y, y_aux) for the fp8 conv5 kinds."""
+    x = np.ascontiguousarray(x, np.float32)
+    weight = np.ascontiguousarray(weight, np.float32)
+    bias = np.ascontiguousarray(bias, np.float32)
+    N, cin, H, W = x.shape
+    cout = weight.shape[0]
+    assert weight.shape == (cout, cin, 3, 3) and bias.shape == (cout,)
+    y = np.empty((N, cout, H, W), np.float32)
+    aux = np.empty((N, 64, H, W), np.float32) if kind in (TRUNK_F8_CONV5, TRUNK_F8_CONV5_RRDB) else None
+    lo = None if lo is None else np.ascontiguousarray(lo, np.float32)
+    skip = None if skip is None else np.ascontiguousarray(skip, np.float32)
+    p = lambda a: None if a is None else a.ctypes.data
+    args = DebugTrunkArgs(kind, form, N, cin, H, W, p(x), p(weight), p(bias), p(lo), p(skip), p(y), p(aux))
+    self._check(self._lib.s2sr_debug_conv_trunk(self._h, C.byref(args)), "s2sr_debug_conv_trunk")
+    return y if aux is None else (y, aux)
+
+
+Engine.debug_config = _debug_config
+Engine.debug_conv_trunk = _debug_conv_trunk
 
 
 def _bench_conv(self, N, H, W, cin, cout, iters=20, trace_wgs=0):

@@ -111,6 +111,13 @@ def _multipart(fields):
     return out, {"content-type": f"multipart/form-data; boundary={b}"}
 
 
+def _jobs(listing):
+    if isinstance(listing, dict):
+        listing = listing.get("jobs", listing)
+        return list(listing.values()) if isinstance(listing, dict) else listing
+    return listing
+
+
 def test_enhance_upload_validation_and_queue(tmp_path, monkeypatch):
     """/api/enhance (reference main.py:544-675) without a GPU: validation codes, the upload lands on disk
     under uploads/<job>/ with the client's file NAME only, jobs beyond the device list queue FIFO and are
@@ -139,6 +146,10 @@ def test_enhance_upload_validation_and_queue(tmp_path, monkeypatch):
     body, hdr = _multipart({"model": (None, b"realesrgan_x4")})
     assert c.post("/api/enhance", content=body, headers=hdr).status_code == 422          # no file
     assert c.post("/api/enhance", content=b"{}", headers={"content-type": "application/json"}).status_code == 422
+    for bad_name in ("", "..", "a/.."):                                                   # no usable file name: 422, and no
+        body, hdr = _multipart({"image": (bad_name, b"x" * 10)})                          # status-less placeholder job is left behind
+        assert c.post("/api/enhance", content=body, headers=hdr).status_code == 422, bad_name
+    assert c.get("/api/sr").json() in ({}, [], {"jobs": []}) or all(j.get("status") for j in _jobs(c.get("/api/sr").json()))
 
     # three uploads on a one-GPU admission list: the TestClient runs background tasks before returning, so
     # drive the first from a thread and watch the other two queue

@@ -387,20 +387,63 @@ def test_hp_tolerance_holds_for_other_weight_draws(seed, gain):
     assert err <= TOL_HP and d.max() <= 1 and np.mean(d == 0) >= 0.99
 
 
-@pytest.mark.parametrize("lo_exp", [9, 12, 16])
-def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir, lo_exp):
+def _fresh(monkeypatch, nb, precision, env, **kw):
+    """Every kernel-form / scale switch is read ONCE, in s2sr_create: a test of a switch must create its handle after
+    setting it (never the module's engine() cache) and check that the handle took it (s2sr_debug_get_config)."""
+    for k in ("S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = native.Engine(num_block=nb, precision=precision)
+    e.load_state_dict(synthetic_state_dict(nb, seed=0, **kw))
+    return e
+
+
+def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir):
     """The trunk's lo half travels as e4m3(lo * 2^lo_exp) planes (conv_trunk_f16 conv5; S2SR_LO_EXP, default 12).  e4m3's own
     exponent covers the range, so the choice of scale only moves where very small / very large |x| lose bits: the HP
-    tolerance holds for 2^9 .. 2^16, and the 8-wave path (fp16 lo, S2SR_TRUNK=0) stays the tighter reference."""
+    tolerance holds for 2^9 .. 2^16, and the 8-wave path (fp16 lo, S2SR_TRUNK=0) stays the tighter reference.  Fresh
+    handles per setting; the five configurations must actually differ."""
     g = np.load(golden_dir / "g4_full_nets.npz")
-    monkeypatch.setenv("S2SR_LO_EXP", str(lo_exp))
-    y = engine(23, native.PREC_F16_HP).forward_f32(g["x"])
-    err = np.abs(y - g["y_b23"]).max()
-    monkeypatch.setenv("S2SR_TRUNK", "0")
-    y16 = engine(23, native.PREC_F16_HP).forward_f32(g["x"])
-    err16 = np.abs(y16 - g["y_b23"]).max()
-    print(f"lo as e4m3 * 2^{lo_exp}: max-abs err {err:.3e}; fp16 lo (8-wave path) {err16:.3e}")
-    assert err <= TOL_HP and err16 <= TOL_HP and err16 <= err * 1.5
+    HP = native.PREC_F16_HP
+    outs = {}
+    for lo_exp in (9, 12, 16):
+        e = _fresh(monkeypatch, 23, HP, {"S2SR_LO_EXP": str(lo_exp)})
+        cfg = e.debug_config()
+        assert cfg["lo_exp"] == lo_exp and cfg["trunk_w4"] == 1, cfg
+        outs[lo_exp] = e.forward_f32(g["x"])
+        e.close()
+    e = _fresh(monkeypatch, 23, HP, {"S2SR_TRUNK": "0"})
+    assert e.debug_config()["trunk_w4"] == 0
+    outs["w8"] = e.forward_f32(g["x"])
+    e.close()
+    errs = {k: float(np.abs(v - g["y_b23"]).max()) for k, v in outs.items()}
+    print("trunk lo as e4m3 * 2^k / fp16 lo on the 8-wave path: max-abs err " + ", ".join(f"{k}: {v:.3e}" for k, v in errs.items()))
+    assert all(v <= TOL_HP for v in errs.values()), errs
+    assert errs["w8"] <= 1.5 * errs[12]
+    # different arithmetic must give different bytes (r02's version of this test compared one cached handle with itself)
+    keys = list(outs)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            assert not np.array_equal(outs[keys[i]], outs[keys[j]]), (keys[i], keys[j])
+    # the default handle is lo_exp 12 on the one-wave-per-SIMD kernels
+    monkeypatch.delenv("S2SR_TRUNK", raising=False)
+    assert np.array_equal(engine(23, HP).forward_f32(g["x"]), outs[12])
+
+
+def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
+    """S2SR_TRUNK=0 keeps the RDB convs on the 8-wave kernel (conv3x3.hip EPI_RDB5 / EPI_RDB5_RRDB epilogues, fp16 lo,
+    3-buffer workspace): the g3 / g4 / g5 goldens in HP and fast mode through a handle created with the switch set."""
+    g3 = np.load(golden_dir / "g3_small_nets.npz")
+    g4 = np.load(golden_dir / "g4_full_nets.npz")
+    for prec, tol in ((native.PREC_F16_HP, TOL_HP), (native.PREC_F16, TOL_F16)):
+        for nb, g, key in ((2, g3, "y_b2"), (6, g4, "y_b6"), (23, g4, "y_b23")):
+            e = _fresh(monkeypatch, nb, prec, {"S2SR_TRUNK": "0"})
+            assert e.debug_config()["trunk_w4"] == 0
+            err = float(np.abs(e.forward_f32(g["x"]) - g[key]).max())
+            e.close()
+            print(f"8-wave RDB path, precision {prec}, {nb} blocks: max-abs err {err:.3e}")
+            assert err <= tol, (prec, nb, err)
 
 
 def test_subpixel_and_upsample_on_load_forms_agree(monkeypatch):
@@ -615,18 +658,23 @@ def test_fp8_mode_full_tile_and_batch_properties():
         assert a.shape == (4 * H, 4 * W, 3) and np.isfinite(a).all() and np.abs(a - b).max() <= TOL_FP8_23, (H, W)
 
 
-@pytest.mark.parametrize("env", [{"S2SR_FP8_LOADER": "0"}, {"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "1"},
-                                 {"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "2"}, {"S2SR_FP8_W8": "1"}])
-def test_fp8_conv14_kernel_forms_agree_bit_for_bit(monkeypatch, env):
+@pytest.mark.parametrize("env,form", [({"S2SR_FP8_LOADER": "0"}, 1), ({"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "1"}, 3),
+                                      ({"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "2"}, 5), ({"S2SR_FP8_W8": "1"}, 8)])
+def test_fp8_conv14_kernel_forms_agree_bit_for_bit(monkeypatch, env, form):
     """The fp8 conv1-4 kernel comes in several forms (a fifth load-only wave or not, weights streamed or resident in LDS,
     one or two waves per SIMD).  They accumulate the same products in the same order, so whichever form the environment
-    selects must give the same bytes as the default."""
+    selects must give the same bytes as the default -- through a FRESH handle whose config shows the form was taken
+    (per layer: tests/test_gpu_trunk.py::test_f8_conv14_forms_agree_bit_for_bit)."""
     from s2sr.synth import synthetic_tiles
     tiles = synthetic_tiles(3, 96, seed=5)
-    y0 = engine(6, native.PREC_FP8).forward_batch_u8(tiles)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    y1 = engine(6, native.PREC_FP8).forward_batch_u8(tiles)
+    e0 = _fresh(monkeypatch, 6, native.PREC_FP8, {})
+    assert e0.debug_config()["fp8_form"] == 0
+    y0 = e0.forward_batch_u8(tiles)
+    e0.close()
+    e1 = _fresh(monkeypatch, 6, native.PREC_FP8, env)
+    assert e1.debug_config()["fp8_form"] == form, e1.debug_config()
+    y1 = e1.forward_batch_u8(tiles)
+    e1.close()
     assert np.array_equal(y0, y1), env
 
 

@@ -28,6 +28,11 @@ def check(path):
     issued after it (vmcnt completes in issue order); until then nothing may touch its destination registers."""
     bad = 0
     kernel = None
+    mfma_at = {}          # AGPR -> wait-state position of the inline-asm MFMA that wrote it last (hipcc does not know these
+                          # asm statements are MFMAs and inserts no hazard nops: a VALU / memory read of the result needs 18
+                          # wait states behind a 16-pass MFMA; dependent MFMAs on the same accumulator are interlocked)
+    pipe_free = 0
+    ws = 0                # wait states so far: 1 per instruction, N + 1 per s_nop N (straight-line count)
     pending = {}          # reg -> (line of the load, index of the load in the vector-memory stream)
     nvm = 0               # vector-memory operations issued so far in this kernel (straight-line count; loops only
                           # make the real distance larger or equal within one trip)
@@ -35,7 +40,7 @@ def check(path):
     for ln, line in enumerate(open(path), 1):
         t = line.strip()
         if t.startswith("_Z") and ":" in t and not t.startswith("_ZZ"):
-            kernel, pending, nvm = t.split(":")[0], {}, 0
+            kernel, pending, nvm, mfma_at, ws, pipe_free = t.split(":")[0], {}, 0, {}, 0, 0
         if t.startswith(";;#ASMSTART"):
             in_asm = True
             continue
@@ -45,6 +50,27 @@ def check(path):
         if not t or t.startswith(";") or t.startswith("."):
             continue
         toks = re.findall(r"[av]\[\d+:\d+\]|[av]\d+", t)
+        mn = re.match(r"s_nop\s+(\d+)", t)
+        if t.startswith("v_mfma"):
+            # the matrix pipe takes one MFMA per `passes` wait states: an MFMA behind another issues when the pipe is free
+            passes = 16 if "32x32x64" in t else 8
+            ws = max(ws + 1, pipe_free)
+            pipe_free = ws + passes
+            if in_asm and toks:
+                for r in regs(toks[0]):
+                    if r.startswith("a"):
+                        mfma_at[r] = (ws, passes + 3)      # LLVM GFX940_XDL_N_PassWriteVgprVALUMemExpReadWaitStates
+        else:
+            ws += int(mn.group(1)) + 1 if mn else 1
+            if mfma_at and not t.startswith("s_"):
+                used = set()
+                for tok in toks:
+                    used |= regs(tok)
+                for r in sorted(used & set(mfma_at)):
+                    at, need = mfma_at.pop(r)
+                    if ws - at < need:
+                        bad += 1
+                        print(f"{path}:{ln}: {kernel}: `{t}` reads {r} {ws - at} wait state(s) behind the inline MFMA that wrote it (need {need})")
         is_vm = bool(re.match(r"(global|buffer|flat|scratch)_(load|store|atomic)", t))
         if in_asm and t.startswith("global_load_dword") and "lds" not in t:
             nvm += 1
