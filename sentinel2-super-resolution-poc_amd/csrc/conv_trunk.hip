@@ -62,6 +62,9 @@
 #define S2SR_DIAG_NOLO 0        // numerics diagnostic (tools/nolo_probe.sh): the fp16 trunk carried WITHOUT its lo half.  Measured: max-abs
                                 // 2.2e-3 .. 3.4e-3 instead of 7e-5 .. 1.8e-4: the pair is what the 1e-3 costs (its lo half needs only e4m3, see the epilogue)
 #endif
+#ifndef S2SR_DIAG_SKIPDY2
+#define S2SR_DIAG_SKIPDY2 0     // timing diagnostic, conv_trunk_f16: 1 = the dy == 2 MFMAs are not issued (results wrong): 2/3 of the MFMA work
+#endif
 #ifndef S2SR_DIAG_NOMFMA
 #define S2SR_DIAG_NOMFMA 0      // timing diagnostic, both kernels: 1 = issue no MFMA (results are wrong).  What is left is the memory
                                 // side of the kernel: profiles/r02_trunk_anatomy.txt section 8
@@ -464,6 +467,14 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     }
                     asm volatile("" : "+a"(acc[ct][np]) : "v"(acol[dx][dy][ct]), "v"(breg[t % 6]));
                     continue;
+#endif
+#if S2SR_DIAG_SKIPDY2
+                    // timing diagnostic only (wrong results): one MFMA in three is not issued (its operand reads stay) -- the MFMA
+                    // count of a row-Winograd F(2,3) form without its transform cost: an upper bound for what that form can buy
+                    if (dy == 2) {
+                        asm volatile("" : "+a"(acc[ct][np]) : "v"(acol[dx][dy][ct]), "v"(breg[t % 6]));
+                        continue;
+                    }
 #endif
                     if (FIRST && dx == 0 && dy == 0) {
                         if (kBiasC) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
