@@ -32,6 +32,7 @@ struct ConvW {
     bool f8trunk = false;
     int32_t* d_wscale = nullptr;
     bool pooled = false;                // d_wpack / d_wscale point into the handle's pools
+    bool wino = false;                  // fp16 RDB conv1-4 packed for the row-Winograd form (conv_wino.hip: 12 U fragments per stage)
 };
 
 // kernel families for the HIP-event statistics
@@ -324,6 +325,10 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     if (epi == EPI_FIRST) bytes += px * 64 * 10.0;        // lo + R + F
     if (epi == EPI_BODY) bytes += px * 64 * 4.0;
     Scope sc(h, st, fam, flops, bytes);
+    if (cw.wino) {
+        HIPCHK(h, launch_conv_trunk_wino(p, st));
+        return S2SR_OK;
+    }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
@@ -723,7 +728,9 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
         const bool trunk = i >= 1 && i + 5 < nconv;
         if (trunk) {
             poff[i] = pool_bytes;
-            pool_bytes += align256(fp8 ? conv_wpack_bytes_f8(specs[i].cin, specs[i].cout) : conv_wpack_bytes(specs[i].cin, specs[i].cout));
+            const bool wino = !fp8 && h->trunk_wino && h->trunk_w4 && specs[i].cout == 32;
+            pool_bytes += align256(fp8 ? conv_wpack_bytes_f8(specs[i].cin, specs[i].cout)
+                                       : wino ? conv_wpack_bytes_wino(specs[i].cin, specs[i].cout) : conv_wpack_bytes(specs[i].cin, specs[i].cout));
         }
     }
     HIPCHK(h, hipMalloc((void**)&h->pool_w, pool_bytes ? pool_bytes : 256));
@@ -771,6 +778,9 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
                 cw.seg_lo_mask = 0;
                 cw.d_wscale = h->pool_s + idx * 64;
                 HIPCHK(h, launch_pack_trunk_f8(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, cw.d_wscale, st));
+            } else if (h->trunk_wino && h->trunk_w4 && s.cout == 32) {
+                cw.wino = true;
+                HIPCHK(h, launch_pack_trunk_wino(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, st));
             } else {
                 HIPCHK(h, launch_pack_trunk_f16(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, st));
             }

@@ -433,6 +433,37 @@ def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir):
     assert np.array_equal(engine(23, HP).forward_f32(g["x"]), outs[12])
 
 
+def test_row_winograd_trunk_goldens(monkeypatch, golden_dir):
+    """S2SR_WINO=1: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip).  Its transformed operands are rounded to
+    fp16 once more than the direct form's; the HP bound must hold all the same (CPU emulation: tools/emulate_r03.py), on the
+    goldens incl. the stress weights, on a full tile against the oracle, and a tile must give the same bytes alone (16x32
+    patch form) and inside a batch (32x32 form)."""
+    g3 = np.load(golden_dir / "g3_small_nets.npz")
+    g4 = np.load(golden_dir / "g4_full_nets.npz")
+    HP = native.PREC_F16_HP
+    for nb, g, key, kw in ((2, g3, "y_b2", {}), (6, g4, "y_b6", {}), (23, g4, "y_b23", {}), (23, g4, "y_b23_gain1", {"body_gain": 1.0})):
+        e = _fresh(monkeypatch, nb, HP, {"S2SR_WINO": "1"}, **kw)
+        assert e.debug_config()["trunk_wino"] == 1
+        err = float(np.abs(e.forward_f32(g["x"]) - g[key]).max())
+        d = float(np.abs(e.forward_f32(g["x"]) - engine(nb, HP, **kw).forward_f32(g["x"])).max())
+        e.close()
+        print(f"row-Winograd trunk, {nb} blocks {kw}: max-abs err {err:.3e} (vs the direct form's output: {d:.3e})")
+        assert err <= TOL_HP and d > 0, (nb, err)
+    from s2sr.synth import synthetic_tiles
+    tiles = synthetic_tiles(8, 256, seed=21)
+    e = _fresh(monkeypatch, 23, HP, {"S2SR_WINO": "1"})
+    y = e.forward_batch_u8(tiles)                       # 512 patches of 32x32: the 32x32 form
+    assert np.array_equal(e.forward_batch_u8(tiles[3:4])[0], y[3])   # 64 patches: the 16x32 form
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    q_ref, f_ref = ref.enhance(tiles[0], ref.to_torch_sd(synthetic_state_dict(23, seed=0)), 23, return_float=True)
+    f = e.enhance_f32(tiles[0])
+    err = float(np.abs(f - f_ref).max())
+    dq = np.abs(y[0].astype(np.int16) - q_ref.astype(np.int16))
+    print(f"row-Winograd trunk, 256x256 tile vs the oracle: float max-abs {err:.3e}, u8 identical {np.mean(dq == 0):.4f}")
+    assert err <= TOL_HP and dq.max() <= 1 and np.mean(dq == 0) > 0.99
+    e.close()
+
+
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
     """S2SR_TRUNK=0 keeps the RDB convs on the 8-wave kernel (conv3x3.hip EPI_RDB5 / EPI_RDB5_RRDB epilogues, fp16 lo,
     3-buffer workspace): the g3 / g4 / g5 goldens in HP and fast mode through a handle created with the switch set."""
