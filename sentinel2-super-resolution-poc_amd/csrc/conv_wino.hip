@@ -73,29 +73,36 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t voff, uint32_t
 template <typename T>
 __device__ __forceinline__ void asm_land(T& r) { asm volatile("" : "+a"(r)); }
 
-// The MFMA statements also carry the ORDER of the transform VALU around them, through operands that cost nothing:
-// `after` (the V this slot's VALU just produced) is a dummy input -- that VALU cannot sink below the MFMA --, and `gate` (a
-// slab row the NEXT slot's VALU reads) passes through as "+v" -- that VALU cannot rise above it.  hipcc places pure VALU
-// freely otherwise (sched_barrier orders the machine scheduler, not instruction selection: without the ties all 16
-// transform instructions of a step ended up in front of its four MFMAs and the matrix pipe idled behind them).
-__device__ __forceinline__ void mfma_acc(f32x16& acc, const f16x8& a, const f16x8& b, const f16x8& after, f16x8& gate) {
-    (void)after;
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0" : "+a"(acc), "+v"(gate) : "v"(a), "v"(b));
+// The MFMAs and the transform VALU are ALL `asm volatile`: volatile statements keep their program order, which is the only
+// way to pin pure VALU between the MFMAs.  (hipcc places compiler-visible VALU freely -- sched_barrier orders the machine
+// scheduler, not instruction selection: as plain C++ all 16 transform instructions of a step ended up in front of its four
+// MFMAs and the matrix pipe idled behind them; operand ties through the MFMA statements work too but cost an s_nop each.)
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ void mfma_first(f32x16& acc, const f16x8& a, const f16x8& b, const f16x8& after, f16x8& gate) {
-    (void)after;
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, 0" : "=a"(acc), "+v"(gate) : "v"(a), "v"(b));
+__device__ __forceinline__ void mfma_first(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
 }
-// a - b in packed fp16, one rounding per element: v_pk_add_f16 with the second operand negated.  Inline asm: a plain vector
-// subtraction (and fma(b, -1, a), which LLVM folds back into it) compiles to v_sub_f16 + v_sub_f16_sdwa + v_pack_b32_f16
-// per dword, three instructions instead of one.  Not volatile: the MFMA statements' operand ties place it.
+// a - b / a + b in packed fp16, one rounding per element.  (A plain vector subtraction -- and fma(b, -1, a), which LLVM folds
+// back into it -- compiles to v_sub_f16 + v_sub_f16_sdwa + v_pack_b32_f16 per dword: three instructions instead of one.)
 __device__ __forceinline__ f16x8 pk_sub(const f16x8& a, const f16x8& b) {
     const u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
     u32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t r;
-        asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x[i]), "v"(y[i]));
+        asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x[i]), "v"(y[i]));
+        o[i] = r;
+    }
+    return __builtin_bit_cast(f16x8, o);
+}
+__device__ __forceinline__ f16x8 pk_add(const f16x8& a, const f16x8& b) {
+    const u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t r;
+        asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(x[i]), "v"(y[i]));
         o[i] = r;
     }
     return __builtin_bit_cast(f16x8, o);
@@ -128,6 +135,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
     const size_t oblk = (size_t)p.Hp * p.Wp * 32;
 
     if (tid < 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
+    if (p.trace && tid == 0) {                                   // diagnostic (tools/wino_anatomy.py): whole-kernel clock stamps
+        p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
+    }
 
     // ---- per-lane global offsets of this wave's PW DMA pieces (patch independent)
     uint32_t loff[G::PW];
@@ -206,7 +217,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
         for (int r = 0; r < 6; ++r) b[r] = *(const f16x8*)(sb + bbase[0] + r * G::ROWB);
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) ac[xi] = *(const f16x8*)(sb + abase + xi * 1024);
-        vc[0] = b[0] - b[2]; vc[1] = b[1] + b[2]; vc[2] = b[2] - b[1]; vc[3] = b[1] - b[3];
+        vc[0] = pk_sub(b[0], b[2]); vc[1] = pk_add(b[1], b[2]); vc[2] = pk_sub(b[2], b[1]); vc[3] = pk_sub(b[1], b[3]);
     }
 
     // One stage = 3 * NT steps u = (dx, t).  Step u:
@@ -254,33 +265,22 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
             }
             // the next tile's four slab rows: rows 2t+2 .. 2t+5 of this column shift, or rows 0..3 of the next one
             const bool wrap = t + 1 == NT;
-            f16x8 d0 = wrap ? bq[0] : b[wrap ? 0 : 2 * t + 2], d1 = wrap ? bq[1] : b[wrap ? 0 : 2 * t + 3],
-                  d2 = wrap ? bq[2] : b[wrap ? 0 : 2 * t + 4], d3 = wrap ? bq[3] : b[wrap ? 0 : 2 * t + 5];
+            const f16x8 d0 = wrap ? bq[0] : b[wrap ? 0 : 2 * t + 2], d1 = wrap ? bq[1] : b[wrap ? 0 : 2 * t + 3],
+                        d2 = wrap ? bq[2] : b[wrap ? 0 : 2 * t + 4], d3 = wrap ? bq[3] : b[wrap ? 0 : 2 * t + 5];
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) {
-                // one V of the next tile per MFMA slot
+                if (FIRST && dx == 0) mfma_first(acc[t][xi], ac[xi], vc[xi]);
+                else mfma_acc(acc[t][xi], ac[xi], vc[xi]);
+                // behind each MFMA: one V of the next tile (4 instructions), and this slot's share of the DMA
                 if (xi == 0) vn[0] = pk_sub(d0, d2);
-                if (xi == 1) vn[1] = d1 + d2;
+                if (xi == 1) vn[1] = pk_add(d1, d2);
                 if (xi == 2) vn[2] = pk_sub(d2, d1);
                 if (xi == 3) vn[3] = pk_sub(d1, d3);
 #pragma unroll
                 for (int sl = 0; sl < G::PW; ++sl)
                     if ((sl * (G::BAR * 4)) / G::PW == u * 4 + xi) dma_piece(sl, dma_off);
                 __builtin_amdgcn_sched_barrier(0);
-                // gate: slot 0 -> d1 (slot 1 reads d1, d2), slot 1 -> d2 (slot 2), slot 2 -> d3 (slot 3), slot 3 -> next step's rows
-                // (rows 0..3 of a new column shift were requested in this very step: no tie on those, it would wait for them)
-                constexpr int dummy_row = 0;
-                const int tn = (t + 1) % NT;
-                const bool tie_next = tn + 1 < NT;
-                f16x8 gdummy = vc[dummy_row];
-                f16x8& gate = xi == 0 ? d1 : xi == 1 ? d2 : xi == 2 ? d3 : (tie_next ? b[tie_next ? 2 * tn + 2 : 0] : gdummy);
-                if (FIRST && dx == 0) mfma_first(acc[t][xi], ac[xi], vc[xi], vn[xi], gate);
-                else mfma_acc(acc[t][xi], ac[xi], vc[xi], vn[xi], gate);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            // rows the asm statements "touched" go back where the later steps read them
-            if (wrap) { bq[1] = d1; bq[2] = d2; bq[3] = d3; }
-            else { b[2 * t + 3] = d1; b[2 * t + 4] = d2; b[2 * t + 5] = d3; }
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) vc[xi] = vn[xi];
             if (t == NT - 1) {
@@ -363,6 +363,10 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
     }
     // nothing may still be on its way into this workgroup's LDS when it ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.trace && tid == 0) {
+        p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
+    }
 }
 
 template <int NP, int R>

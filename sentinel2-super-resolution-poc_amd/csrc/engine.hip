@@ -1477,14 +1477,15 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
     const size_t wn = (size_t)Cout * Cin * 9;
     HIPCHK(h, hipMalloc(&d_w32.p, wn * 4));
     HIPCHK(h, hipMemcpyAsync(d_w32.p, a->weight, wn * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMalloc(&d_wp.p, f8 ? conv_wpack_bytes_f8(Cin, Cout) : conv_wpack_bytes(Cin, Cout)));
+    const bool wino = kind == 0 && a->form == 3;
+    HIPCHK(h, hipMalloc(&d_wp.p, f8 ? conv_wpack_bytes_f8(Cin, Cout) : wino ? conv_wpack_bytes_wino(Cin, Cout) : conv_wpack_bytes(Cin, Cout)));
     HIPCHK(h, hipMalloc(&d_b.p, 64 * 4));
     HIPCHK(h, hipMalloc(&d_ws.p, 64 * 4));
     float bb[64] = {0};
     memcpy(bb, a->bias, Cout * sizeof(float));
     HIPCHK(h, hipMemcpyAsync(d_b.p, bb, sizeof bb, hipMemcpyHostToDevice, st));
     if (f8) HIPCHK(h, launch_pack_trunk_f8((const float*)d_w32.p, Cin, Cout, d_wp.p, (int32_t*)d_ws.p, st));
-    else if (kind == 0 && a->form == 3) HIPCHK(h, launch_pack_trunk_wino((const float*)d_w32.p, Cin, Cout, d_wp.p, st));
+    else if (wino) HIPCHK(h, launch_pack_trunk_wino((const float*)d_w32.p, Cin, Cout, d_wp.p, st));
     else HIPCHK(h, launch_pack_trunk_f16((const float*)d_w32.p, Cin, Cout, d_wp.p, st));
     // ---- activations: the dense tensor D (12 fp16 blocks per image, or 6 e4m3 planes), packed on the host
     const int xe = h->fp8_x_exp, ge = h->fp8_g_exp, le = h->lo_exp;
@@ -1553,7 +1554,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
             }
         }
         hipError_t e;
-        if (kind == 0 && a->form == 3) e = launch_conv_trunk_wino(p, st);
+        if (wino) e = launch_conv_trunk_wino(p, st);
         else e = launch_conv_trunk(p, Cout / 32, epi, st, false, kind == 0 ? a->form : 0);
         if (e != hipSuccess) return fail(h, S2SR_E_HIP, std::string("launch_conv_trunk: ") + hipGetErrorString(e));
     } else {
@@ -1655,7 +1656,8 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     char* T = nullptr;
     float *Rr = nullptr, *d_b = nullptr;
     unsigned long long* d_tr = nullptr;
-    const size_t wb = conv_wpack_bytes(cin, cout), db = (size_t)N * 12 * blk;
+    const bool wino = h->trunk_wino && h->trunk_w4 && cout == 32;
+    const size_t wb = wino ? conv_wpack_bytes_wino(cin, cout) : conv_wpack_bytes(cin, cout), db = (size_t)N * 12 * blk;
     HIPCHK(h, hipMalloc((void**)&D0, db));
     HIPCHK(h, hipMalloc((void**)&D1, db));
     HIPCHK(h, hipMalloc((void**)&T, (size_t)N * 4 * blk));
@@ -1695,6 +1697,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
         p.trace = d_tr;
     }
     auto launch_one = [&](bool tr) -> hipError_t {
+        if (wino) return launch_conv_trunk_wino(p, st);           // stamps whenever p.trace is set
         if (h->trunk_w4) {
             const hipError_t e = launch_conv_trunk(p, ct, epi, st, tr);
             if (e != hipErrorNotSupported) return e;

@@ -24,10 +24,21 @@ TOL_HP = 3e-4      # S2SR_PREC_F16_HP: split-operand head/tail convs (the north 
 _ENG = {}
 
 
+_SWITCHES = ("S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
+             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH")
+
+
 def engine(nb, precision=native.PREC_F16, **kw):
+    """Cached DEFAULT-configuration engines.  s2sr_create reads every S2SR_* switch once, so the cache is filled with the
+    switches cleared, whatever a test has put into the environment: a cached handle never carries a test's setting."""
+    import os
     key = (nb, precision, tuple(sorted(kw.items())))
     if key not in _ENG:
-        e = native.Engine(num_block=nb, precision=precision)
+        saved = {k: os.environ.pop(k) for k in _SWITCHES if k in os.environ}
+        try:
+            e = native.Engine(num_block=nb, precision=precision)
+        finally:
+            os.environ.update(saved)
         e.load_state_dict(synthetic_state_dict(nb, seed=0, **kw))
         _ENG[key] = e
     return _ENG[key]
@@ -390,7 +401,7 @@ def test_hp_tolerance_holds_for_other_weight_draws(seed, gain):
 def _fresh(monkeypatch, nb, precision, env, **kw):
     """Every kernel-form / scale switch is read ONCE, in s2sr_create: a test of a switch must create its handle after
     setting it (never the module's engine() cache) and check that the handle took it (s2sr_debug_get_config)."""
-    for k in ("S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO"):
+    for k in _SWITCHES:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -445,7 +456,9 @@ def test_row_winograd_trunk_goldens(monkeypatch, golden_dir):
         e = _fresh(monkeypatch, nb, HP, {"S2SR_WINO": "1"}, **kw)
         assert e.debug_config()["trunk_wino"] == 1
         err = float(np.abs(e.forward_f32(g["x"]) - g[key]).max())
-        d = float(np.abs(e.forward_f32(g["x"]) - engine(nb, HP, **kw).forward_f32(g["x"])).max())
+        e0 = _fresh(monkeypatch, nb, HP, {}, **kw)           # the direct form, on a handle created WITHOUT the switch
+        d = float(np.abs(e.forward_f32(g["x"]) - e0.forward_f32(g["x"])).max())
+        e0.close()
         e.close()
         print(f"row-Winograd trunk, {nb} blocks {kw}: max-abs err {err:.3e} (vs the direct form's output: {d:.3e})")
         assert err <= TOL_HP and d > 0, (nb, err)
