@@ -41,10 +41,20 @@ BATCH = 32
 NUM_BLOCK = 23
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seed_tiles: np.ndarray) -> dict:
-    """The oracle (CPU restatement of RealESRGAN.enhance, fp32 torch) timed on this host's
-    cores on a bounded sample of the same workload.  Checker code used as a reported baseline
-    only -- nothing of it is on the product path."""
+    """The oracle (CPU restatement of RealESRGAN.enhance, fp32 torch) timed on this host's cores on a bounded sample of
+    the same workload (n = all cores and n = 1).  Checker code used as a reported baseline only --
+    nothing of it is on the product path."""
     from oracle import rrdbnet_ref as ref
     try:
         avail = len(os.sched_getaffinity(0))
@@ -59,9 +69,21 @@ def cpu_baseline(seed_tiles: np.ndarray) -> dict:
     for i in range(n):
         ref.enhance(seed_tiles[i], sd, NUM_BLOCK)
     dt = (time.perf_counter() - t0) / n
+    # one thread: a 64x64 corner of a tile (1/16 of its pixels; the net is convolutional, cost per pixel is the same)
+    torch.set_num_threads(1)
+    ref.enhance(seed_tiles[0][:32, :32], sd, NUM_BLOCK)
+    t1 = time.perf_counter()
+    ref.enhance(seed_tiles[0][:64, :64], sd, NUM_BLOCK)
+    dt1 = (time.perf_counter() - t1) * 16.0
+    torch.set_num_threads(cores)
+    flop_tile = TILE * TILE * FLOP_PER_LR_PX
     return {"value": round(16 * TILE * TILE / 1e6 / dt, 4), "unit": "SR-MP/s", "cores": cores, "kind": "port",
-            "sample": f"{n} tiles of {TILE}x{TILE}x3 through the fp32 oracle (23 blocks) after a 64x64 warm-up; "
-                      f"{dt:.2f} s/tile", "s_per_tile": round(dt, 3)}
+            "cpu_model": cpu_model(), "cores_available": avail,
+            "sample": f"{n} tiles of {TILE}x{TILE}x3 through the fp32 oracle (23 blocks) on {cores} threads after a 64x64 warm-up: "
+                      f"{dt:.2f} s/tile; one thread: one 64x64 corner of a tile (1/16 of its pixels) scaled x16: {dt1:.1f} s/tile",
+            "s_per_tile": round(dt, 3), "GFLOP_per_s": round(flop_tile / dt / 1e9, 1),
+            "one_thread": {"value": round(16 * TILE * TILE / 1e6 / dt1, 5), "unit": "SR-MP/s", "cores": 1, "s_per_tile": round(dt1, 2),
+                           "GFLOP_per_s": round(flop_tile / dt1 / 1e9, 1)}}
 
 
 class ClockSampler:
@@ -115,6 +137,81 @@ class ClockSampler:
                 "samples": len(fs)}
 
 
+PRECISION_TEXT = {
+    "hp": ("fp16 MFMA operands, fp32 accumulate, trunk as an (fp16 hi, e4m3 lo) pair; the 6 convs outside the RRDB trunk with split "
+           "operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 8e-5..1.9e-4 vs the fp32 reference"),
+    "fp8": ("the 345 RDB convs on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, per-tensor-kind "
+            "activation scales, fp32 accumulate, fp16 trunk); head/tail convs in plain fp16 (S2SR_FP8_TAIL=hp for the split forms): "
+            "measured max-abs 4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference, u8 within 1 LSB (93-95 % of bytes identical) -- NOT inside "
+            "the 1e-3 tolerance: an opt-in mode, not one to ship the reference's outputs with"),
+    "fast": "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference",
+}
+HBM_PEAK_GBS = 8000.0        # spec peak, MI355X_MICROARCH.md
+HBM_ACHIEVABLE_TBS = 6.3     # what a streaming copy achieves on this part (same guide)
+PROF_EVERY = 7               # coprime with the period of the conv1..4 (4) and conv5 / conv5-of-rdb3 (3) launch sequences; bracketing
+                             # EVERY launch puts two marker packets between all kernels and inflates a 70 us kernel's time by ~13 %
+                             # against rocprofv3's kernel duration (measured), every 7th agrees within 2 %
+
+
+def roofline_block(stats: dict, precision: str, group: int, batch: int, dt_prof: float, steps: int, g0, g1) -> dict:
+    """the network's roof is the MFMA (dense fp16 2.5 PFLOP/s; block-scaled fp8 5 PFLOP/s).
+    `frac` = algorithmic FLOP of the dominant kernel family / its HIP-event time / that peak.  The per-launch HBM view of the
+    same kernels (a layer-by-layer schedule moves 224-260 FLOP per byte, below the machine balance of 312) rides along as
+    `hbm_view`; it is NOT the headline roof."""
+    PEAK = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_F16_PEAK_TFLOPS
+    conv = {k: v for k, v in stats.items() if v["launches"] and v["flops"] > 0}
+    dom = max(conv, key=lambda k: conv[k]["total_ms"])
+    d = conv[dom]
+    achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+    rdb_ms = sum(conv[k]["total_ms"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
+    rdb_fl = sum(conv[k]["flops"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
+    # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (tools/prof_pmc.sh -> profiles/pmc_summary.json:
+    # FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate passes); rocprofv3 cannot run inside this process.
+    traffic, traffic_source = None, None
+    imgs = min(group if group > 0 else (32 if precision == "fp8" else 16), batch)   # images per launch (engine group)
+    pmc = REPO / "profiles" / "pmc_summary.json"
+    if pmc.exists():
+        try:
+            pj = json.loads(pmc.read_text())
+            per_img = pj.get(("fp8:" if precision == "fp8" else "") + dom, {}).get("hbm_bytes_per_image")
+            traffic = per_img * imgs if per_img else None
+            meta = pj.get("_meta", {})
+            traffic_source = {"file": str(pmc.relative_to(REPO)), "group": meta.get("group"), "git_rev": meta.get("git_rev"),
+                              "precision": meta.get("precision"), "scaled_to_group": imgs,
+                              "note": "counters come from a separate rocprofv3 --pmc run at the named revision (the kernels' byte "
+                                      "counts do not change with scheduling edits; re-collected whenever a kernel's traffic does)"}
+        except Exception:
+            traffic = None
+
+    def hbm_ceiling(v):
+        return v["flops"] / v["bytes"] * HBM_ACHIEVABLE_TBS if v["bytes"] else None
+    alg_gbs = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+    return {
+        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_flop_per_launch": round(d["flops"] / d["launches"]),
+        "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+        "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
+        "rdb_convs_TFLOP_per_s": round(rdb_fl / (rdb_ms * 1e-3) / 1e12, 1) if rdb_ms else None,
+        "rdb_convs_frac": round(rdb_fl / (rdb_ms * 1e-3) / 1e12 / PEAK, 4) if rdb_ms else None,
+        "hbm_view": {"note": "the same launches against the HBM roof: algorithmic bytes of a layer-by-layer schedule / event time",
+                     "achieved": round(alg_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 4),
+                     "arithmetic_intensity_FLOP_per_B": round(d["flops"] / d["bytes"], 1),
+                     "machine_balance_FLOP_per_B": round(PEAK * 1e3 / HBM_PEAK_GBS, 1),
+                     "hbm_ceiling_TFLOP_per_s": round(hbm_ceiling(d), 1),
+                     "frac_of_hbm_ceiling": round(achieved / hbm_ceiling(d), 4),
+                     "hbm_ceiling_note": "arithmetic intensity x 6.3 TB/s (streaming-copy rate); with their MFMAs compiled out the trunk "
+                                         "kernels run at 5.1-5.4 TB/s algorithmic (profiles/r02_trunk_anatomy.txt section 8)"},
+        "stats_pass": {"every": PROF_EVERY, "ms_per_step": round(dt_prof / steps * 1e3, 3),
+                       "note": "separate pass after the timed region, direct launches + hipEvents on the launch stream"},
+        "timed_pass": {"graph_replays": g1[1] - g0[1], "graph_captures_total": g1[0]},
+        "families": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
+                         "TFLOP_per_s": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["total_ms"] else 0,
+                         "alg_GB_per_s": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else 0,
+                         "frac_of_mfma_peak": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / PEAK, 4) if v["total_ms"] else 0}
+                     for k, v in stats.items() if v["launches"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +220,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--group", type=int, default=int(os.environ.get("S2SR_GROUP", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp8 / AOI / single-tile-latency legs behind the headline")
     ap.add_argument("--precision", choices=["hp", "fast", "fp8"], default="hp",
                     help="hp: split-operand head/tail convs, <=1e-4 of the fp32 reference (meets the north star's 1e-3); "
                          "fast: plain fp16 operands everywhere, 2e-3; fp8: BASELINE configs[4] -- the 345 RDB convs on e4m3 "
@@ -144,6 +242,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    backend = None
     if world > 1 or os.environ.get("S2SR_FORCE_DIST") == "1":   # the env knob rehearses the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -161,47 +260,49 @@ def main():
         blob = torch.empty(nparam, dtype=torch.float32, device=dev)
     if dist is not None:
         dist.broadcast(blob, src=0)
-    prec = {"hp": native.PREC_F16_HP, "fast": native.PREC_F16, "fp8": native.PREC_FP8}[a.precision]
-    eng = native.Engine(num_block=NUM_BLOCK, device=local, group=a.group, precision=prec)
-    torch.cuda.current_stream().synchronize()
-    eng.load_blob_dev(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)   # device blob in, no host tensor
-    del blob
+    PREC = {"hp": native.PREC_F16_HP, "fast": native.PREC_F16, "fp8": native.PREC_FP8}
+
+    def make_engine(precision: str):
+        e = native.Engine(num_block=NUM_BLOCK, device=local, group=a.group, precision=PREC[precision])
+        torch.cuda.current_stream().synchronize()
+        e.load_blob_dev(blob.data_ptr(), blob.numel(), torch.cuda.current_stream().cuda_stream)   # device blob in, no host tensor
+        return e
+    eng = make_engine(a.precision)
 
     # ---- synthetic inputs, resident in HBM before the timed region ------
     B = a.batch
     tiles_np = synthetic_tiles(B, TILE, seed=1234 + rank)
     x = torch.from_numpy(tiles_np).to(dev)
-    y = torch.empty((B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev)
-    y2 = torch.empty_like(y) if a.enhance_crops else None
-    gathered = torch.empty((world * B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) if dist is not None else None
     # the product launches on a real stream (the legacy null stream cannot replay hipGraphs)
     side = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
     prm = native.pp_wow()
 
-    # N > 1: the all-gather of step i runs on a communication stream while step i + 1 computes into the other output buffer
-    # (two output / gather buffer sets; an event per buffer in each direction).  Every gather lies inside the timed region:
-    # the closing synchronize waits for both streams.
+    # N > 1: the all-gather of step i runs on a communication stream while step i + 1 computes into the other output buffer.
+    # ONE double buffer, sized once before the loop: two output sets and two gather sets (world x 96 MiB each at 32 tiles per
+    # rank; an event per buffer in each direction).  Every gather lies inside the timed region: the closing synchronize
+    # waits for both streams.
     nbuf = 2 if dist is not None else 1
-    ys = [y] + [torch.empty_like(y) for _ in range(nbuf - 1)]
-    y2s = ([y2] + [torch.empty_like(y2) for _ in range(nbuf - 1)]) if a.enhance_crops else None
-    gs = [gathered] + [torch.empty_like(gathered) for _ in range(nbuf - 1)] if dist is not None else None
+    ys = [torch.empty((B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    y2s = [torch.empty_like(ys[0]) for _ in range(nbuf)] if a.enhance_crops else None
+    gs = [torch.empty((world * B, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)] if dist is not None else None
     comm = torch.cuda.Stream(device=dev) if dist is not None else None
     ev_done = [torch.cuda.Event() for _ in range(nbuf)]
     ev_gath = [torch.cuda.Event() for _ in range(nbuf)]
     gath_pending = [False] * nbuf
     step_no = [0]
 
-    def step():
+    def step(e=None):
+        e = e or eng
         b = step_no[0] % nbuf
         step_no[0] += 1
         if gath_pending[b]:
             side.wait_event(ev_gath[b])            # the gather that read this buffer set last has finished
-        eng.forward_batch_u8_dev(x.data_ptr(), B, TILE, TILE, ys[b].data_ptr(), stream)
+        e.forward_batch_u8_dev(x.data_ptr(), B, TILE, TILE, ys[b].data_ptr(), stream)
         out = ys[b]
         if a.enhance_crops:
-            eng.postprocess_batch_u8_dev(ys[b].data_ptr(), B, 4 * TILE, 4 * TILE, prm, y2s[b].data_ptr(), stream)
+            e.postprocess_batch_u8_dev(ys[b].data_ptr(), B, 4 * TILE, 4 * TILE, prm, y2s[b].data_ptr(), stream)
             out = y2s[b]
         if dist is not None:
             ev_done[b].record(side)
@@ -215,93 +316,54 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(max(a.warmup, 2 * nbuf)):      # the second sighting of a (group, buffers) pair captures its hipGraph
-        step()
-    torch.cuda.synchronize()
-    barrier()
+    def timed(e, steps, warmup, sample_clock):
+        """W warm-up steps (the second sighting of a (group, buffers) pair captures its hipGraph), then exactly K steps on the
+        product's launch path (hipGraph replay of each group, no events inside) bracketed by barrier + synchronize on both
+        sides; then a second, separate pass of the same K steps with a hipEvent pair around every 7th launch of each kernel
+        family (direct launches: events cannot sit inside a graph) for the per-kernel figures -- `value` never comes from it."""
+        for _ in range(max(warmup, 2 * nbuf)):
+            step(e)
+        torch.cuda.synchronize()
+        barrier()
+        e.set_profiling(0)
+        torch.cuda.synchronize()
+        barrier()
+        sampler = ClockSampler(local) if sample_clock else None
+        if sampler:
+            sampler.start()
+        g0 = e.graph_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(e)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        g1 = e.graph_stats()
+        clocks = sampler.stop() if sampler else None
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        e.set_profiling(PROF_EVERY)
+        e.reset_kernel_stats()
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(steps):
+            step(e)
+        torch.cuda.synchronize()
+        dt_prof = time.perf_counter() - tp0
+        stats = e.kernel_stats()
+        e.set_profiling(0)
+        barrier()
+        return dt, dt_prof, stats, g0, g1, clocks
 
-    # ---- timed region: exactly K steps on the product's launch path (hipGraph replay of each group,
-    # no events inside) bracketed by barrier + synchronize on both sides.
-    eng.set_profiling(0)
-    torch.cuda.synchronize()
-    barrier()
-    sampler = ClockSampler(local) if rank == 0 else None
-    if sampler:
-        sampler.start()
-    g0 = eng.graph_stats()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    g1 = eng.graph_stats()
-    clocks = sampler.stop() if sampler else None
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dt_prof, stats, g0, g1, clocks = timed(eng, a.steps, a.warmup, rank == 0)
 
-    # ---- second, separate pass for the per-kernel figures: the same K steps with a hipEvent pair on the
-    # launch stream around every 7th launch of each kernel family (direct launches: events cannot sit
-    # inside a graph).  `value` never comes from this pass.
-    PROF_EVERY = 7        # coprime with the period of the conv1..4 (4) and conv5 / conv5-of-rdb3 (3) launch sequences; bracketing
-                          # EVERY launch puts two marker packets between all kernels and inflates a 70 us kernel's time by ~13 %
-                          # against rocprofv3's kernel duration (measured), every 7th agrees within 2 %
-    eng.set_profiling(PROF_EVERY)
-    eng.reset_kernel_stats()
-    torch.cuda.synchronize()
-    tp0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    dt_prof = time.perf_counter() - tp0
-    stats = eng.kernel_stats()
-    eng.set_profiling(0)
-    barrier()
-
-    PEAK = MFMA_FP8_PEAK_TFLOPS if a.precision == "fp8" else MFMA_F16_PEAK_TFLOPS   # of the dominant (RDB conv) kernels
     if rank == 0:
         ms = dt / a.steps * 1e3
         tiles_per_s = world * B * a.steps / dt
         value = tiles_per_s * 16 * TILE * TILE / 1e6
-        # dominant kernel family by device time
-        conv = {k: v for k, v in stats.items() if v["launches"] and v["flops"] > 0}
-        dom = max(conv, key=lambda k: conv[k]["total_ms"])
-        d = conv[dom]
-        achieved = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
-        rdb_ms = sum(conv[k]["total_ms"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
-        rdb_fl = sum(conv[k]["flops"] for k in ("rdb_conv1-4", "rdb_conv5") if k in conv)
-        # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (tools/prof_pmc.sh ->
-        # profiles/pmc_summary.json: FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate passes);
-        # rocprofv3 cannot run inside this process, so the figure is read from the committed summary.
-        traffic, traffic_source = None, None
-        imgs = min(a.group if a.group > 0 else (32 if a.precision == "fp8" else 16), B)   # images per launch (engine group)
-        pmc = REPO / "profiles" / "pmc_summary.json"
-        if pmc.exists():
-            try:
-                pj = json.loads(pmc.read_text())
-                ent = pj.get(dom, {})
-                per_img = ent.get("hbm_bytes_per_image")
-                traffic = per_img * imgs if per_img else None
-                traffic_source = {"file": "profiles/pmc_summary.json", "group": pj.get("_meta", {}).get("group"),
-                                  "git_rev": pj.get("_meta", {}).get("git_rev"), "precision": pj.get("_meta", {}).get("precision"),
-                                  "scaled_to_group": imgs}
-            except Exception:
-                traffic = None
-        # Which roof binds the dominant kernel: its arithmetic intensity (algorithmic FLOP / algorithmic HBM byte of a
-        # layer-by-layer schedule; measured traffic is within 3-4 % of that, profiles/pmc_summary.json) against the
-        # machine balance.  fp16 RDB convs: 224-260 FLOP/B against 2500/8 = 312 -> HBM is the lower roof; fp8: 400-450
-        # against 5000/8 = 625 -> HBM again.  The no-MFMA diagnostic builds (S2SR_DIAG_NOMFMA, profiles/
-        # r02_trunk_anatomy.txt section 8) agree: with every MFMA removed the same kernels still take 70-86 % of their time.
-        HBM_PEAK_GBS = 8000.0        # spec peak, MI355X_MICROARCH.md
-        HBM_ACHIEVABLE_TBS = 6.3     # what a streaming copy achieves on this part (same guide)
-
-        def hbm_ceiling(v):
-            return v["flops"] / v["bytes"] * HBM_ACHIEVABLE_TBS if v["bytes"] else None
-        hbm_roof_tflops = d["flops"] / d["bytes"] * HBM_PEAK_GBS / 1e3
-        alg_gbs = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
-        hbm_bound = hbm_roof_tflops < PEAK
+        PEAK = MFMA_FP8_PEAK_TFLOPS if a.precision == "fp8" else MFMA_F16_PEAK_TFLOPS
         line = {
             "metric": "SR megapixels/sec (whole node) on 256x256 RGB tiles, x4",
             "value": round(value, 2), "unit": "SR-MP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -316,44 +378,57 @@ def main():
                        "flop_note": "TFLOP/s figures count the reference net's FLOPs (2*9*Cin*Cout per output pixel); the two "
                                     "up-convs execute 4/9 of theirs (sub-pixel form), 2.3 % of the net",
                        "group": a.group, "weights": "seeded synthetic RealESRGAN_x4plus shapes (seed 0)",
-                       "precision": ("fp16 MFMA operands, fp32 accumulate, trunk as an (fp16 hi, e4m3 lo) pair; the 6 convs outside the "
-                                     "RRDB trunk with split operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 8e-5..1.9e-4 vs the fp32 reference"
-                                     if a.precision == "hp" else
-                                     "the 345 RDB convs on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, "
-                                     "per-tensor-kind activation scales, fp32 accumulate, fp16 trunk); head/tail convs in plain fp16 (S2SR_FP8_TAIL=hp for the split forms): measured max-abs "
-                                     "4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference, u8 within 1 LSB (93-95 % of bytes identical) -- NOT inside the 1e-3 tolerance"
-                                     if a.precision == "fp8" else
-                                     "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference")},
-            "roofline": {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom,
-                         "achieved": round(alg_gbs, 1) if hbm_bound else round(achieved, 1),
-                         "peak": HBM_PEAK_GBS if hbm_bound else PEAK, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                         "frac": round(alg_gbs / HBM_PEAK_GBS, 4) if hbm_bound else round(achieved / PEAK, 4),
-                         "arithmetic_intensity_FLOP_per_B": round(d["flops"] / d["bytes"], 1),
-                         "machine_balance_FLOP_per_B": round(PEAK * 1e3 / HBM_PEAK_GBS, 1),
-                         "mfma": {"achieved": round(achieved, 1), "peak": PEAK, "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4),
-                                  "hbm_roof_TFLOP_per_s": round(hbm_roof_tflops, 1)},
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                         "hbm_ceiling_TFLOP_per_s": round(hbm_ceiling(d), 1),
-                         "frac_of_hbm_ceiling": round(achieved / hbm_ceiling(d), 4),
-                         "hbm_ceiling_note": "hbm_ceiling = arithmetic intensity x 6.3 TB/s (streaming-copy rate); the trunk kernels with their "
-                                             "MFMAs compiled out run at 5.1-5.4 TB/s algorithmic (profiles/r02_trunk_anatomy.txt section 8)",
-                         "avg_launch_us": round(d["total_ms"] / d["launches"] * 1e3, 2), "launches": d["launches"],
-                         "stats_pass": {"every": PROF_EVERY, "ms_per_step": round(dt_prof / a.steps * 1e3, 3),
-                                        "note": "separate pass after the timed region, direct launches + hipEvents"},
-                         "timed_pass": {"graph_replays": g1[1] - g0[1], "graph_captures_total": g1[0]},
-                         "rdb_convs_TFLOP_per_s": round(rdb_fl / (rdb_ms * 1e-3) / 1e12, 1) if rdb_ms else None,
-                         "rdb_convs_frac": round(rdb_fl / (rdb_ms * 1e-3) / 1e12 / PEAK, 4) if rdb_ms else None,
-                         "families": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
-                                          "TFLOP_per_s": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["total_ms"] else 0,
-                                          "alg_GB_per_s": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9, 1) if v["total_ms"] else 0,
-                                          "frac_of_hbm_peak": round(v["bytes"] / (v["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v["total_ms"] else 0,
-                                          "hbm_ceiling_TFLOP_per_s": round(hbm_ceiling(v), 1) if v["flops"] and v["bytes"] else None}
-                                      for k, v in stats.items() if v["launches"]}},
+                       "precision": PRECISION_TEXT[a.precision],
+                       "rccl_ranks_seen": dist.get_world_size() if dist is not None else 1,
+                       "collective_backend": backend if dist is not None else None},
+            "roofline": roofline_block(stats, a.precision, a.group, B, dt_prof, a.steps, g0, g1),
         }
         if clocks:   # what the cap leaves: the same dense peak at the clock the part actually held
             pk = PEAK * clocks["sclk_mhz"] / 2400.0
-            line["roofline"]["held_clock"] = dict(clocks, peak_at_clock=round(pk, 1), frac_at_clock=round(achieved / pk, 4))
+            line["roofline"]["held_clock"] = dict(clocks, peak_at_clock=round(pk, 1),
+                                                  frac_at_clock=round(line["roofline"]["achieved"] / pk, 4))
+
+    # ---- behind the headline, same process, one GPU only: the fp8 line, the path /api/wow really takes, one tile's latency
+    if world == 1 and not a.no_secondary:
+        sec = {}
+        if a.precision != "fp8":
+            e8 = make_engine("fp8")
+            dt8, dtp8, st8, h0, h1, _ = timed(e8, a.steps, a.warmup, False)
+            v8 = B * a.steps / dt8 * 16 * TILE * TILE / 1e6
+            sec["fp8"] = {"value": round(v8, 2), "unit": "SR-MP/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3), "dtype": "f8e4m3",
+                          "tolerance": "max-abs 4.1e-3 vs the fp32 reference (tests/test_gpu_net.py test_fp8_mode_*): OUTSIDE the 1e-3 "
+                                       "target; BASELINE configs[4] arithmetic, opt-in (S2SR_PRECISION=fp8 / S2SR_FARM_PRECISION=fp8)",
+                          "precision": PRECISION_TEXT["fp8"], "roofline": roofline_block(st8, "fp8", a.group, B, dtp8, a.steps, h0, h1)}
+            e8.close()
+            del e8
+        # AOI mosaic through the reference's entry point (s2sr_enhance_u8: host image in, host image out, the reference's
+        # 256/10 window plan = 256 windows of 276x276), seed 4321
+        aoi_n = 4096
+        aoi = np.random.Generator(np.random.PCG64(4321)).integers(0, 256, size=(aoi_n, aoi_n, 3), dtype=np.uint8)
+        eng.enhance_u8(aoi[:1024, :1024])           # warm-up: workspace for 276x276 windows, graphs
+        eng.enhance_u8(aoi)
+        t0 = time.perf_counter()
+        out = eng.enhance_u8(aoi)
+        dta = time.perf_counter() - t0
+        nwin = len(native.plan_tiles(aoi_n, aoi_n, 256, 10))
+        sec["aoi"] = {"value": round(16 * aoi_n * aoi_n / 1e6 / dta, 1), "unit": "SR-MP/s", "seconds": round(dta, 3),
+                      "workload": f"{aoi_n}x{aoi_n}x3 u8 host image -> {4 * aoi_n}x{4 * aoi_n} u8 host image through s2sr_enhance_u8, "
+                                  f"reference plan 256/10: {nwin} windows of 276x276, {a.precision} mode; includes H2D / D2H and the stitch",
+                      "ideal_at_batch_rate_s": round(nwin * (276 * 276) / (256 * 256) / (B * a.steps / dt), 3)}
+        del out, aoi
+        # one 256x256 tile, device-resident in and out, on the launch stream (351 dependent launches, replayed as one graph)
+        y1 = torch.empty((1, 4 * TILE, 4 * TILE, 3), dtype=torch.uint8, device=dev)
+        for _ in range(4):
+            eng.forward_batch_u8_dev(x.data_ptr(), 1, TILE, TILE, y1.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.forward_batch_u8_dev(x.data_ptr(), 1, TILE, TILE, y1.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sec["latency_ms_1tile"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+        if rank == 0:
+            line["secondary"] = sec
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tiles_np)
         print(json.dumps(line), flush=True)

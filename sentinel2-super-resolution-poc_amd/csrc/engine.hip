@@ -126,7 +126,7 @@ struct s2sr_handle {
     int fp8_x_exp = 3, fp8_g_exp = 5;   // S2SR_PREC_FP8 activation scales 2^e of the x / growth planes (S2SR_FP8_XEXP, S2SR_FP8_GEXP); calibrated
                                         // on the synthetic set: profiles/r02_fp8_scale_sweep.txt (|x| up to 56, |x_k| up to 14 before clipping)
     int fp8_x_exp0 = 3, fp8_g_exp0 = 5; // ... as s2sr_create left them: every weight load starts from these again (a calibration belongs to the weights it saw)
-    bool trunk_wino = false;      // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1
+    int trunk_wino = 0;           // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1: all four, 2: conv2-4 only (Cin >= 96)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     std::vector<GraphEntry> graphs;
@@ -665,7 +665,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     h->fp8_x_exp0 = h->fp8_x_exp; h->fp8_g_exp0 = h->fp8_g_exp;
-    if (const char* g = getenv("S2SR_WINO")) h->trunk_wino = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_WINO")) h->trunk_wino = atoi(g) == 2 ? 2 : (atoi(g) != 0 ? 1 : 0);
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
@@ -728,7 +728,7 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
         const bool trunk = i >= 1 && i + 5 < nconv;
         if (trunk) {
             poff[i] = pool_bytes;
-            const bool wino = !fp8 && h->trunk_wino && h->trunk_w4 && specs[i].cout == 32;
+            const bool wino = !fp8 && h->trunk_wino && h->trunk_w4 && specs[i].cout == 32 && (h->trunk_wino == 1 || specs[i].cin >= 96);
             pool_bytes += align256(fp8 ? conv_wpack_bytes_f8(specs[i].cin, specs[i].cout)
                                        : wino ? conv_wpack_bytes_wino(specs[i].cin, specs[i].cout) : conv_wpack_bytes(specs[i].cin, specs[i].cout));
         }
@@ -778,7 +778,7 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
                 cw.seg_lo_mask = 0;
                 cw.d_wscale = h->pool_s + idx * 64;
                 HIPCHK(h, launch_pack_trunk_f8(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, cw.d_wscale, st));
-            } else if (h->trunk_wino && h->trunk_w4 && s.cout == 32) {
+            } else if (h->trunk_wino && h->trunk_w4 && s.cout == 32 && (h->trunk_wino == 1 || s.cin >= 96)) {
                 cw.wino = true;
                 HIPCHK(h, launch_pack_trunk_wino(d_blob + woff[idx], s.cin, s.cout, cw.d_wpack, st));
             } else {
@@ -1437,7 +1437,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino;
     return S2SR_OK;
 }
 

@@ -95,13 +95,14 @@ class NativeBackend:
         return out
 
 
-def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10, dst=None, enhance_crops=None):
+def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10, dst=0, enhance_crops=None):
     """`RealESRGAN.enhance` (cnn_super_resolution.py:217-280) with the windows of the tiled branch
     sharded over the process group.  Every rank passes the same image.
 
-    dst=None: all-gather -- every rank gets the mosaic.  dst=r: the window outputs are
-    gathered to rank r only (one consumer, e.g. the rank that writes the GeoTIFF): 1/world of the
-    all-gather's traffic per link; the other ranks return None.
+    dst=r (default 0): the window outputs are gathered to rank r only -- the one consumer of a job's mosaic (the rank
+    that post-processes it and writes the GeoTIFF): 1/world of an all-gather's traffic per link; the other ranks return
+    None.  dst=None: all-gather -- every rank gets the mosaic (world x the receive traffic and a full mosaic
+    per rank, only for callers that really consume it everywhere).
     enhance_crops: post-process parameters (native.pp_wow() / pp_farm()) or None.  The mosaic is BGR like
     everything `enhance` handles (wow_sr.py:85,94); the post-process runs on its RGB view, on the
     consuming rank(s), over the WHOLE mosaic after the stitch -- CLAHE's 8x8 grid is image-global

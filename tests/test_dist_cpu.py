@@ -71,7 +71,7 @@ def _worker(rank, world, port, cases, q):
     res = []
     for (H, W, tile, pad, seed) in cases:
         img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
-        res.append(sd.enhance_distributed(be, img, tile, pad))
+        res.append(sd.enhance_distributed(be, img, tile, pad, dst=None))      # all-gather form: every rank gets the mosaic
     tiles = np.random.default_rng(99).integers(0, 256, (5, 8, 12, 3), dtype=np.uint8)
     res.append(sd.forward_batch_distributed(be, tiles))
     # gather-to-one-consumer form (+ the image-global post-process composed behind the stitch)
@@ -79,6 +79,10 @@ def _worker(rank, world, port, cases, q):
     img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
     g = sd.enhance_distributed(be, img, tile, pad, dst=world - 1, enhance_crops=object())
     assert (g is None) == (rank != world - 1)
+    g0 = sd.enhance_distributed(be, img, tile, pad)                  # the default: gather to rank 0, the job's one consumer
+    assert (g0 is None) == (rank != 0)
+    if rank == 0:
+        assert np.array_equal(g0, res[0])
     if rank == world - 1:
         assert np.array_equal(g, (255 - res[0][:, :, ::-1])[:, :, ::-1])
     blob = sd.broadcast_weights(synthetic_state_dict(1, seed=3) if rank == 0 else None, 1, torch.device("cpu")).numpy()

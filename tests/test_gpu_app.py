@@ -206,6 +206,53 @@ def test_http_enhance_upload_runs_on_gpu(monkeypatch, tmp_path):
     assert out.shape == (80, 112, 3) and np.mean(d == 0) > 0.9
 
 
+def test_http_enhance_on_the_references_upload_matches_its_recorded_result(monkeypatch, tmp_path, golden_dir):
+    """The reference's recorded /api/enhance job replayed on the GPU: its own upload (576x432, decoded pixels in
+    g8_real_image.npz, re-encoded losslessly as PNG) with model realesrgan_anime -> the job's `result` must have the recorded
+    metadata JSON's keys, value types and non-path values (tests/golden/ref_wow_sr_metadata_anime.json, written by the
+    reference's process_wow_sr, wow_sr.py:243-259), and the SR pixels must be the reference net's (through the oracle's
+    post-process: the net output may differ by 1 LSB, which CLAHE / unsharp amplify)."""
+    import json
+    from fastapi.testclient import TestClient
+    from app.sr_routes import create_app
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    want = json.loads((golden_dir / "ref_wow_sr_metadata_anime.json").read_text())
+    g8 = np.load(golden_dir / "g8_real_image.npz")
+    rgb = np.ascontiguousarray(g8["img_bgr"][:, :, ::-1])
+    png = tmp_path / "1758691019_vin.png"
+    rio.write_png(png, rgb)
+    b = "BoUnD"
+    body = (f'--{b}\r\nContent-Disposition: form-data; name="model"\r\n\r\nrealesrgan_anime\r\n'
+            f'--{b}\r\nContent-Disposition: form-data; name="image"; filename="1758691019_vin.png"\r\n'
+            f'Content-Type: image/png\r\n\r\n').encode() + png.read_bytes() + f"\r\n--{b}--\r\n".encode()
+    c = TestClient(create_app(tmp_path / "data", tiler=False, devices=[0]))
+    r = c.post("/api/enhance", content=body, headers={"content-type": f"multipart/form-data; boundary={b}"})
+    assert r.status_code == 200, r.text
+    st = c.get(f"/api/sr/{r.json()['job_id']}").json()
+    assert st["status"] == "completed", st
+    got = st["result"]
+
+    def shape(v):
+        if isinstance(v, dict):
+            return {k: shape(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [shape(x) for x in v]
+        return type(v).__name__
+    assert list(got) == list(want) and shape(got) == shape(want) and got["outputs"]["sr_tif"] is None
+    for k, v in want["sr_metadata"].items():
+        if k not in ("input_file", "output_file"):
+            assert got["sr_metadata"][k] == v, k
+    out, _ = rio.read_rgb_u8(got["outputs"]["sr_png"])
+    assert list(out.shape[:2]) == want["sr_metadata"]["output_size"] == [2304, 1728]
+    # pixels: the recorded windows of the reference net's u8 output (BGR), post-processed by the oracle on the WHOLE image is
+    # not available (the fixture holds windows), so check the SR stage alone through the class, then the job's own composition
+    import app.cnn_super_resolution as m
+    sr = m.RealESRGAN(model_name="realesrgan_anime").enhance(g8["img_bgr"])
+    for (y, x), wq in zip(g8["full_win_yx"], g8["full_win_u8_b6"]):
+        assert np.abs(sr[y:y + 64, x:x + 64].astype(np.int16) - wq.astype(np.int16)).max() <= 1
+    assert np.array_equal(out, pp.enhance_for_crops(np.ascontiguousarray(sr[:, :, ::-1])))
+
+
 def test_farm_sr_on_fp8_trunk(monkeypatch, tmp_path):
     """BASELINE.json configs[4]: the /api/sr variant (process_farm_sr) selected onto the fp8 trunk by
     S2SR_FARM_PRECISION=fp8; pixels stay within the mode's measured tolerance of the default-precision job."""

@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
 
 TOL_F16 = 2.5e-3
 TOL_HP = 3e-4      # S2SR_PREC_F16_HP: split-operand head/tail convs (the north star's 1e-3 with margin)
+# S2SR_PREC_FP8 is NOT inside the north star's 1e-3 (e4m3 keeps 3 mantissa bits); its tolerance is what it measures, see below
+TOL_FP8_23 = 1e-2
+TOL_FP8_STRESS = 3e-2
+TOL_FP8_6 = 1e-3
 
 
 _ENG = {}
@@ -87,6 +91,44 @@ def test_hp_mode_meets_1e3(golden_dir):
     g6 = np.load(golden_dir / "g6_tiled_small.npz")
     f6 = engine(1, HP).enhance_f32(g6["img"], tile=int(g6["tile_size"]), pad=int(g6["tile_pad"]))
     assert np.abs(f6 - g6["out_f32"]).max() <= TOL_HP
+
+
+def test_real_image_golden(golden_dir):
+    """The reference's own upload (data/uploads/.../1758691019_vin.jpg, decoded pixels in g8_real_image.npz) through the
+    IMPORTED reference net: natural-image statistics (flat areas, text edges, JPEG blocks) instead of noise.  A 64x96 crop
+    through the 23- and 6-block nets, and the whole 576x432 image (non-square, whole-image branch of enhance()) through the
+    6-block net at eight 64x64 output windows.  HP: float <= 3e-4, u8 <= 1 LSB; fast <= 2.5e-3; fp8: what it measures."""
+    g = np.load(golden_dir / "g8_real_image.npz")
+    crop = g["crop_bgr"]
+    for nb in (23, 6):
+        want_f, want_q = g[f"crop_out_f32_b{nb}"], g[f"crop_out_u8_b{nb}"]
+        for prec, name, tol in ((native.PREC_F16_HP, "hp", TOL_HP), (native.PREC_F16, "fast", TOL_F16), (native.PREC_FP8, "fp8", None)):
+            e = engine(nb, prec)
+            f = e.enhance_f32(crop)
+            q = e.enhance_u8(crop)
+            d = np.abs(f - want_f)
+            dq = np.abs(q.astype(np.int16) - want_q.astype(np.int16))
+            print(f"real image crop, {nb} blocks, {name}: float max-abs {d.max():.3e} rms {np.sqrt((d ** 2).mean()):.3e} "
+                  f"(|y| max {np.abs(want_f).max():.2f}); u8 max {dq.max()} LSB, identical {np.mean(dq == 0):.4f}")
+            if tol is not None:
+                assert d.max() <= tol and dq.max() <= 1 and np.mean(dq == 0) >= (0.99 if prec == native.PREC_F16_HP else 0.9), (nb, name)
+            else:       # fp8 is outside the 1e-3 tolerance by construction; its bound on natural statistics is pinned here
+                assert np.isfinite(f).all() and d.max() <= (TOL_FP8_23 if nb == 23 else TOL_FP8_6) and dq.max() <= 4, (nb, name)
+    e = engine(6, native.PREC_F16_HP)
+    img = g["img_bgr"]
+    assert img.shape == (576, 432, 3) and img.shape[0] * img.shape[1] <= 4 * 256 * 256
+    f = e.enhance_f32(img)
+    q = e.enhance_u8(img)
+    assert f.shape == (2304, 1728, 3)
+    worst, same = 0.0, []
+    for (y, x), wf, wq in zip(g["full_win_yx"], g["full_win_f32_b6"], g["full_win_u8_b6"]):
+        worst = max(worst, float(np.abs(f[y:y + 64, x:x + 64] - wf).max()))
+        dq = np.abs(q[y:y + 64, x:x + 64].astype(np.int16) - wq.astype(np.int16))
+        assert dq.max() <= 1
+        same.append(np.mean(dq == 0))
+    print(f"real image 576x432 whole, 6 blocks, hp: float max-abs over 8 windows {worst:.3e}, u8 identical {min(same):.4f}+; "
+          f"output mean {f.mean(dtype=np.float64):.6f} (reference {g['full_mean_std_b6'][0]:.6f})")
+    assert worst <= TOL_HP and min(same) >= 0.99 and abs(f.mean(dtype=np.float64) - g["full_mean_std_b6"][0]) <= 1e-5
 
 
 def test_g4_u8_entry_matches_f32_entry(golden_dir):
@@ -207,7 +249,7 @@ def test_cut_forward_stitch_equals_enhance():
             dist_all = dist.all_gather_into_tensor
             dist.all_gather_into_tensor = lambda out, inp: out.copy_(inp)
             try:
-                got = enhance_distributed(be, img, ts, tp)
+                got = enhance_distributed(be, img, ts, tp, dst=None)
             finally:
                 dist.all_gather_into_tensor = dist_all
             assert np.array_equal(got, exp), (H, W)
@@ -623,8 +665,8 @@ def test_rccl_world1_path():
         rng = np.random.default_rng(41)
         img = rng.integers(0, 256, size=(70, 90, 3), dtype=np.uint8)
         exp = ref_e.enhance_u8(img, tile=32, pad=4)
-        assert np.array_equal(enhance_distributed(be, img, 32, 4), exp)
-        assert np.array_equal(enhance_distributed(be, img, 32, 4, dst=0), exp)
+        assert np.array_equal(enhance_distributed(be, img, 32, 4, dst=None), exp)     # all-gather (RCCL)
+        assert np.array_equal(enhance_distributed(be, img, 32, 4), exp)               # default: gather to rank 0
         tiles = rng.integers(0, 256, size=(5, 24, 40, 3), dtype=np.uint8)
         assert np.array_equal(forward_batch_distributed(be, tiles), ref_e.forward_batch_u8(tiles))
         e.close()
@@ -646,9 +688,6 @@ def test_rccl_world1_path():
 # is NOT inside the north star's 1e-3; its tolerance is what it measures (MI355X, seeded x4plus-shaped weights):
 #   23 blocks: max-abs 3.5e-3 (rms 8.0e-4) on the golden at |y| max 2.7, 4.1e-3 (rms 6.2e-4) on a 256x256 tile;
 #   unscaled-body stress weights 1.0e-2;  6 blocks 1.1e-4;  u8 within 1 LSB (93-95 % of bytes identical)
-TOL_FP8_23 = 1e-2
-TOL_FP8_STRESS = 3e-2
-TOL_FP8_6 = 1e-3
 
 
 def test_fp8_mode_measured_tolerance(golden_dir):

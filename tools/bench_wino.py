@@ -3,7 +3,7 @@
 HP mode, 32 tiles per step, per-family HIP-event stats, A/B/A/B."""
 import os, subprocess, sys
 for rep in (1, 2):
-    for w in ("0", "1"):
+    for w in ("0", "1", "2"):
         env = dict(os.environ, S2SR_WINO=w)
         print(f"== S2SR_WINO={w} rep {rep}", flush=True)
         out = subprocess.run([sys.executable, "tools/quick_bench.py", "--batch", "32", "--steps", "4", "--hp", "1"], env=env, capture_output=True, text=True, timeout=300)

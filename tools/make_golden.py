@@ -176,6 +176,51 @@ def main():
     assert ref_keys == list(synthetic_state_dict(23).keys()), "key order differs from the reference"
     np.savez_compressed(OUT / "g7_weightgen.npz", **rec)
 
+    # G8: the one REAL image the reference holds (data/uploads/wow_20260114_144253/1758691019_vin.jpg, 432 wide x 576 high,
+    # the input of its two recorded /api/enhance jobs): natural-image statistics instead of noise.  Decoded here with
+    # PIL (the decoded pixels are the fixture; the GPU box never decodes the JPEG) and fed in BGR order as wow_sr.py:85,94
+    # does.  (a) a 64x96 crop through the 23- and 6-block nets: u8 in, float + u8 out; (b) the full image (248,832 px <=
+    # 4 * 256^2: the WHOLE-image branch of enhance(), non-square) through the 6-block net: eight 64x64 output windows of
+    # the float image + the u8 image at the same windows + mean / std of the whole output (the full 1728x2304 float image
+    # would be 48 MB).
+    from PIL import Image
+    jpg = Path("/root/reference/data/uploads/wow_20260114_144253/1758691019_vin.jpg")
+    rgb = np.asarray(Image.open(jpg).convert("RGB"))
+    assert rgb.shape == (576, 432, 3), rgb.shape
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    crop = np.ascontiguousarray(bgr[256:320, 160:256])                   # 64 x 96: text, edges and flat areas
+    rec8 = {"img_bgr": bgr, "crop_bgr": crop, "crop_yx": np.array([256, 160], np.int32)}
+    for nb in (23, 6):
+        net = make_net(nb)
+        e = make_esrgan(net)
+        t = torch.from_numpy(crop.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+        out_f = net(t).squeeze(0).permute(1, 2, 0).numpy()
+        out_u8 = e.enhance(crop)
+        assert np.array_equal((out_f * 255.0).clip(0, 255).astype(np.uint8), out_u8)
+        rec8[f"crop_out_f32_b{nb}"] = out_f
+        rec8[f"crop_out_u8_b{nb}"] = out_u8
+    net6 = make_net(6)
+    e6f = make_esrgan(net6)
+    assert bgr.shape[0] * bgr.shape[1] <= 256 * 256 * 4                   # whole-image branch (cnn_super_resolution.py:226)
+    full_u8 = e6f.enhance(bgr)
+    tf = torch.from_numpy(bgr.astype(np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+    full_f = net6(tf).squeeze(0).permute(1, 2, 0).numpy()
+    assert np.array_equal((full_f * 255.0).clip(0, 255).astype(np.uint8), full_u8) and full_u8.shape == (2304, 1728, 3)
+    wins = np.array([(0, 0), (2240, 1664), (0, 1664), (2240, 0), (1000, 800), (400, 1200), (1700, 300), (1152, 864)], np.int32)
+    rec8["full_win_yx"] = wins
+    rec8["full_win_f32_b6"] = np.stack([full_f[y:y + 64, x:x + 64] for y, x in wins])
+    rec8["full_win_u8_b6"] = np.stack([full_u8[y:y + 64, x:x + 64] for y, x in wins])
+    rec8["full_mean_std_b6"] = np.array([full_f.mean(dtype=np.float64), full_f.std(dtype=np.float64)])
+    np.savez_compressed(OUT / "g8_real_image.npz", **rec8)
+
+    # The reference's own recorded job results and tile metadata (data, not source): the output schema of process_wow_sr
+    # (wow_sr.py:166-182,243-259; PNG input -> "sr_tif": null) for both models, and tiling.py's tileset.json contract.
+    import shutil
+    for src, dst in (("data/wow/wow_20260114_144253/1758691019_vin_wow_sr_metadata.json", "ref_wow_sr_metadata_x4.json"),
+                     ("data/wow/wow_20260114_144104/1758691019_vin_wow_sr_metadata.json", "ref_wow_sr_metadata_anime.json"),
+                     ("data/tiles_wow/tileset.json", "ref_tileset.json")):
+        shutil.copyfile(Path("/root/reference") / src, OUT / dst)
+
     tot = sum(os.path.getsize(OUT / f) for f in os.listdir(OUT))
     print("golden fixtures written:", sorted(os.listdir(OUT)), f"{tot / 1e6:.2f} MB")
 
