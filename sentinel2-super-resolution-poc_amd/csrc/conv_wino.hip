@@ -32,6 +32,10 @@
 
 #include "s2sr_internal.h"
 
+#ifndef S2SR_WINO_DIAG_NOXFORM
+#define S2SR_WINO_DIAG_NOXFORM 0
+#endif
+
 namespace s2sr {
 
 namespace {
@@ -272,10 +276,18 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
                 if (FIRST && dx == 0) mfma_first(acc[t][xi], ac[xi], vc[xi]);
                 else mfma_acc(acc[t][xi], ac[xi], vc[xi]);
                 // behind each MFMA: one V of the next tile (4 instructions), and this slot's share of the DMA
+#if S2SR_WINO_DIAG_NOXFORM
+                // timing diagnostic only (wrong results): no transform instructions -- what the 4 packed adds per MFMA cost
+                if (xi == 0) vn[0] = d0;
+                if (xi == 1) vn[1] = d1;
+                if (xi == 2) vn[2] = d2;
+                if (xi == 3) vn[3] = d3;
+#else
                 if (xi == 0) vn[0] = pk_sub(d0, d2);
                 if (xi == 1) vn[1] = pk_add(d1, d2);
                 if (xi == 2) vn[2] = pk_sub(d2, d1);
                 if (xi == 3) vn[3] = pk_sub(d1, d3);
+#endif
 #pragma unroll
                 for (int sl = 0; sl < G::PW; ++sl)
                     if ((sl * (G::BAR * 4)) / G::PW == u * 4 + xi) dma_piece(sl, dma_off);
