@@ -53,6 +53,11 @@
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
+#ifndef S2SR_F16_ACCV
+#define S2SR_F16_ACCV 1    // conv_trunk_f16 conv1-4: accumulators (and the bias C operand) in architectural VGPRs instead of AGPRs (76 + 128 + 16
+                           // registers fit the 256): the epilogue reads them in place, 128 v_accvgpr_read per patch and wave less.  Same bytes out;
+                           // measured (tools/ab_macro.sh, A/B/A/B on one box) conv1-4 73.4 -> 72.0 us per launch, step 85.9 -> 85.4 ms
+#endif
 #ifndef S2SR_F16_PULL
 #define S2SR_F16_PULL 0         // conv_trunk_f16 conv5: 1 = the DMA quota of a patch's first stage is issued inside the previous patch's epilogue
                                 // (the slot is free by then), so the ring does not run down while the wave converts and stores.  Measured
@@ -172,6 +177,19 @@ __device__ __forceinline__ void mfma_first(f32x16& acc, const f16x8& a, const f1
 __device__ __forceinline__ void mfma_first_bias(f32x16& acc, const f16x8& a, const f16x8& b, const f32x16& bias) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&a"(acc) : "v"(a), "v"(b), "a"(bias));
 }
+// the same three with C / D in ARCHITECTURAL VGPRs (S2SR_F16_ACCV, conv1-4 form: 76 + 128 + 16 registers fit the 256):
+// the epilogue's VALU then reads the results in place instead of through 128 v_accvgpr_read per patch and wave
+__device__ __forceinline__ void mfma_acc_v(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first_v(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first_bias_v(f32x16& acc, const f16x8& a, const f16x8& b, const f32x16& bias) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
+}
+template <typename T>
+__device__ __forceinline__ void asm_land_v(T& r) { asm volatile("" : "+v"(r)); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int N>
@@ -206,7 +224,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;
     if (my_tiles <= 0) return;                                   // workgroup-uniform
     const int NS = p.nstage;
-    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {          // whole-kernel clock stamps (tools/trunk_anatomy.py)
+    if (TRACE && p.trace && !(p.dbg & 20) && tid == 0) {         // whole-kernel clock stamps (tools/trunk_anatomy.py)
         p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
     }
@@ -310,6 +328,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
     // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
     constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
+    constexpr bool kAccV = (EPI == EPI_LRELU) && S2SR_F16_ACCV && !TRACE;
     constexpr bool kPull = kTrunk && (S2SR_F16_PULL != 0) && G::PFW == 0;
     f32x16 bacc[kBiasC ? CT : 1];
     if (kBiasC) {
@@ -320,7 +339,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = p.bias[ct * 32 + 8 * g + 4 * hh + i];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+        for (int ct = 0; ct < CT; ++ct) {
+            if (kAccV) asm volatile("" : "+v"(bacc[kBiasC ? ct : 0]));
+            else asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+        }
     }
     f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
     f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
@@ -424,6 +446,12 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                     if (kglob == 4) p.trace[(size_t)blockIdx.x * 24 + 0 * 8 + wave] = __builtin_amdgcn_s_memtime();
                     if (kglob == 5) p.trace[(size_t)blockIdx.x * 24 + 1 * 8 + wave] = __builtin_amdgcn_s_memtime();
                 }
+                if (TRACE && p.trace && (p.dbg & 16) && lane == 0) {   // patch-boundary anatomy (tools/trace_boundary.py)
+                    if (kglob == 2 * NS - 2) p.trace[(size_t)blockIdx.x * 24 + 20 + wave] = __builtin_amdgcn_s_memtime();   // barrier of patch 1's last-but-one stage
+                    if (kglob == 2 * NS - 1) p.trace[(size_t)blockIdx.x * 24 + 4 + wave] = __builtin_amdgcn_s_memtime();    // ... of its last stage
+                    if (kglob == 2 * NS) p.trace[(size_t)blockIdx.x * 24 + 16 + wave] = __builtin_amdgcn_s_memtime();       // ... of patch 2's first stage
+                    if (kglob == 2 * NS + 1) p.trace[(size_t)blockIdx.x * 24 + 12 + wave] = __builtin_amdgcn_s_memtime();   // ... of its second stage
+                }
             }
             // B fragment of step t+3
             {
@@ -476,6 +504,13 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         continue;
                     }
 #endif
+                    if (kAccV) {
+                        if (FIRST && dx == 0 && dy == 0) {
+                            if (kBiasC) mfma_first_bias_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
+                            else mfma_first_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                        } else mfma_acc_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
+                        continue;
+                    }
                     if (FIRST && dx == 0 && dy == 0) {
                         if (kBiasC) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
                         else mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
@@ -494,6 +529,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     auto epilogue = [&](int it) __attribute__((always_inline)) {
         // the MFMA results must have left the matrix pipe before the VALU reads them; hipcc does not know these
         // asm statements are MFMAs, so the wait states are spelled out (16-pass MFMA: 18 needed)
+        if (TRACE && p.trace && (p.dbg & 16) && lane == 0 && it == 1) p.trace[(size_t)blockIdx.x * 24 + 0 + wave] = __builtin_amdgcn_s_memtime();
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         // ... and tied to the data: every accumulator passes through an empty "+a" statement BEHIND the nops, so no read of
         // it (hipcc hoisted 16-17 v_accvgpr_read above the nops before this; tools/check_asm_loads.py now counts the wait
@@ -501,7 +537,10 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int np = 0; np < NP; ++np) asm_land(acc[ct][np]);
+            for (int np = 0; np < NP; ++np) {
+                if (kAccV) asm_land_v(acc[ct][np]);
+                else asm_land(acc[ct][np]);
+            }
         const int tile = it * nwg + slot_in_round;
         const int n = tile / tpi;
         const int trem = tile - n * tpi;
@@ -677,6 +716,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     using std::integral_constant;
     for (int it = 0; it < my_tiles; ++it) {
         const bool first_patch = it == 0;
+        if (TRACE && p.trace && (p.dbg & 16) && lane == 0 && it == 2) p.trace[(size_t)blockIdx.x * 24 + 8 + wave] = __builtin_amdgcn_s_memtime();   // epilogue of patch 1 left
         if (kTrunk) {   // NS >= 4 (host): stages 0..3 are the 64 channels of x
             stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch);
             stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false);
@@ -693,7 +733,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     }
     // nothing may still be on its way into this workgroup's LDS when it ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (TRACE && p.trace && !(p.dbg & 4) && tid == 0) {
+    if (TRACE && p.trace && !(p.dbg & 20) && tid == 0) {
         p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
     }

@@ -6,11 +6,18 @@ for f in sys.argv[1:]:
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         r = d["roofline"]
+        hv = r.get("hbm_view", {})
         print(f"{f}: {d['value']} {d['unit']}  {d['ms_per_step']} ms/step  dtype {d['dtype']}  dominant {r['kernel']} bound {r['bound']} {r['achieved']} {r['unit']} "
-              f"frac {r['frac']}  mfma {r.get('mfma')}  rdb {r['rdb_convs_TFLOP_per_s']}  hbm-ceiling {r['hbm_ceiling_TFLOP_per_s']}  timed {r['timed_pass']}  "
-              f"clock {r.get('held_clock')}")
+              f"frac {r['frac']}  rdb {r['rdb_convs_TFLOP_per_s']} ({r['rdb_convs_frac']})  hbm view {hv.get('achieved')} GB/s ({hv.get('frac')})  "
+              f"timed {r['timed_pass']}  clock {r.get('held_clock')}")
         print("   " + "  ".join(f"{k}: {v['ms']} ms {v['TFLOP_per_s']} TF/s" for k, v in r["families"].items()))
+        s = d.get("secondary", {})
+        if "fp8" in s:
+            print(f"   fp8: {s['fp8']['value']} SR-MP/s {s['fp8']['ms_per_step']} ms/step frac {s['fp8']['roofline']['frac']}")
+        if "aoi" in s:
+            print(f"   aoi: {s['aoi']['value']} SR-MP/s in {s['aoi']['seconds']} s (ideal {s['aoi']['ideal_at_batch_rate_s']} s); 1 tile {s.get('latency_ms_1tile')} ms")
         if "cpu_baseline" in d:
-            print("   cpu:", d["cpu_baseline"])
+            c = d["cpu_baseline"]
+            print(f"   cpu: {c['value']} SR-MP/s on {c['cores']} threads of {c.get('cpu_model')}; one thread {c.get('one_thread', {}).get('value')}")
     except Exception as e:
         print(f, "ERR", e)
