@@ -102,7 +102,9 @@ def test_real_image_golden(golden_dir):
     crop = g["crop_bgr"]
     for nb in (23, 6):
         want_f, want_q = g[f"crop_out_f32_b{nb}"], g[f"crop_out_u8_b{nb}"]
-        for prec, name, tol in ((native.PREC_F16_HP, "hp", TOL_HP), (native.PREC_F16, "fast", TOL_F16), (native.PREC_FP8, "fp8", None)):
+        # fast mode: 1.9e-3 on the noise goldens, 2.8e-3 here (|y| max 3.5 instead of 2.7: its error scales with the signal) -- the
+        # bound for natural statistics is pinned at 3.5e-3; the HP bound needs no such allowance (measured 1.5e-4)
+        for prec, name, tol in ((native.PREC_F16_HP, "hp", TOL_HP), (native.PREC_F16, "fast", 3.5e-3), (native.PREC_FP8, "fp8", None)):
             e = engine(nb, prec)
             f = e.enhance_f32(crop)
             q = e.enhance_u8(crop)
