@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = (y < p.H) && (x < p.W);
+            ok[np] = px_live(p, y, x);
             opix[np] = PH >= 0 ? (size_t)(2 * y + PY + 1) * p.Wp + (2 * x + 1)    // sub-pixel form: row parity PY, column parity q added per tile
                                : (size_t)(y + 1) * p.Wp + (x + 1);
         }
@@ -638,18 +638,28 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(res0[ct][np][g][i], v[i]);
                     }
                     if (EPI == EPI_LAST || EPI == EPI_DEBUG) {
+                        // where the pixel goes: image n of [N, H, W], or -- window mosaic -- window (n*ky + wy)*kx + wx of [count, ry, rx]
+                        size_t oimg = (size_t)n;
+                        int oy = y, ox = x, oH = p.H, oW = p.W;
+                        bool live = ok[np];
+                        if (p.mos_py) {
+                            const int wy = y / p.mos_py, wx = x / p.mos_px;
+                            const int t = (n * p.mos_ky + wy) * p.mos_kx + wx;
+                            live = live && t < p.mos_count;
+                            oimg = (size_t)t; oy = y - wy * p.mos_py; ox = x - wx * p.mos_px; oH = p.mos_ry; oW = p.mos_rx;
+                        }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int co = cb + i;
-                            if (co >= p.cout || !ok[np]) continue;
+                            if (co >= p.cout || !live) continue;
                             float o = v[i];
                             if (EPI == EPI_LAST && g == 0 && p.fold_lo) o = __fadd_rn(o, acc[ct][np][4 + i]);   // + x*w_lo (couts 8..)
                             if (EPI == EPI_DEBUG && p.act) o = lrelu(o);
-                            if (p.out_f32) p.out_f32[(((size_t)n * p.cout + co) * p.H + y) * p.W + x] = o;
+                            if (p.out_f32) p.out_f32[((oimg * p.cout + co) * oH + oy) * oW + ox] = o;
                             if (EPI == EPI_LAST && p.out_u8) {
                                 // (out*255).clip(0,255).astype(uint8): truncation (cnn_super_resolution.py:232)
                                 const float q = fminf(fmaxf(__fmul_rn(o, 255.0f), 0.f), 255.f);
-                                p.out_u8[(((size_t)n * p.H + y) * p.W + x) * 3 + co] = (uint8_t)(int)q;
+                                p.out_u8[((oimg * oH + oy) * oW + ox) * 3 + co] = (uint8_t)(int)q;
                             }
                         }
                     } else {

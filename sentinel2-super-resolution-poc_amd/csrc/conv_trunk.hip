@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = (y < p.H) && (x < p.W);
+            ok[np] = px_live(p, y, x);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t ln = (size_t)n * 2 * oblk;   // image offset inside the e4m3 lo tensors, bytes
@@ -1257,7 +1257,7 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = (y < p.H) && (x < p.W);
+            ok[np] = px_live(p, y, x);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t xn = (size_t)n * p.xh_img;

@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
             for (int j = 0; j < 2; ++j) {
                 const int np = 2 * t + j;
                 const int y = y0 + wave * NP + np;
-                const bool ok = (y < p.H) && (x < p.W);
+                const bool ok = px_live(p, y, x);
                 const size_t opix = (size_t)(y + 1) * p.Wp + (x + 1);
                 u32x2 hpk[4];
 #pragma unroll

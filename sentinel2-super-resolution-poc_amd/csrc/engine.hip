@@ -65,6 +65,7 @@ struct Workspace {
     char *Xh[3] = {nullptr, nullptr, nullptr};
     char *Tz = nullptr;
     bool hp = false, fp8 = false;
+    int mos_py = 0, mos_px = 0;          // separator periods of the window mosaic these planes were zeroed for (0: plain images)
     int Hp = 0, Wp = 0, Hp2 = 0, Wp2 = 0, Hp4 = 0, Wp4 = 0;
     size_t blk1 = 0, blk2 = 0, blk4 = 0;   // bytes of one block plane at 1x / 2x / 4x
 };
@@ -79,8 +80,15 @@ struct EvRec {
 // 351 dependent launches; small groups are launch-bound (~15 us per launch against a few us of
 // work), so the second time the same (shape, buffers) group shows up it is captured into a
 // hipGraph and replayed from then on.
+// Window mosaic geometry of one forward (see ConvParams::mos_*): kx x ky windows of wh x ww per image, `count` windows in all.
+struct Mosaic {
+    int kx = 1, ky = 1, wh = 0, ww = 0, count = 0;
+    bool on() const { return wh > 0; }
+};
+
 struct GraphEntry {
     int n = 0, th = 0, tw = 0;
+    int mos_kx = 0, mos_ky = 0, mos_count = 0;
     const void *in_u8 = nullptr, *in_f32 = nullptr;
     void *out_u8 = nullptr, *out_f32 = nullptr;
     hipStream_t st = nullptr;
@@ -129,6 +137,7 @@ struct s2sr_handle {
     int trunk_wino = 0;           // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1: all four, 2: conv2-4 only (Cin >= 96)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
+    bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     int64_t graph_replays = 0, graph_captures = 0;
@@ -205,18 +214,20 @@ int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int ensure_workspace(s2sr_handle* h, int G, int H, int W) {
+int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mos_px = 0) {
     Workspace& w = h->ws;
     const bool fp8 = h->cfg.precision == S2SR_PREC_FP8;
     const bool hp = h->cfg.precision == S2SR_PREC_F16_HP || (fp8 && h->fp8_hp_tail);   // split-operand head / tail convs
-    if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp && w.fp8 == fp8) return S2SR_OK;
+    // a mosaic's separator rows / columns are conv zero padding: they must come from the allocation memset, so planes that
+    // were written as plain images (or as a mosaic of another period) are not reused
+    if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp && w.fp8 == fp8 && w.mos_py == mos_py && w.mos_px == mos_px) return S2SR_OK;
     if (w.base) {
         HIPCHK(h, hipDeviceSynchronize());
         drop_graphs(h);
         HIPCHK(h, hipFree(w.base));
         w = Workspace();
     }
-    w.G = G; w.H = H; w.W = W; w.hp = hp; w.fp8 = fp8;
+    w.G = G; w.H = H; w.W = W; w.hp = hp; w.fp8 = fp8; w.mos_py = mos_py; w.mos_px = mos_px;
     w.Hp = padded(H); w.Wp = padded(W);
     w.Hp2 = padded(2 * H); w.Wp2 = padded(2 * W);
     w.Hp4 = padded(4 * H); w.Wp4 = padded(4 * W);
@@ -361,12 +372,19 @@ int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams 
 // (:85-91, :103-107).  The torch.cat of the dense block is "the first k blocks of D[cur]",
 // never a copy; conv5 writes the next x into the other dense tensor because neighbouring
 // workgroups still read this one's x as halo.
-int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f32, uint8_t* d_out_u8) {
+int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f32, uint8_t* d_out_u8, const Mosaic& mo = Mosaic()) {
     Workspace& w = h->ws;
     const int nb = h->cfg.num_block;
+    // window mosaic: every launch gets the separator geometry at the scale of the coordinates its epilogue works in
+    auto mosaic_at = [&](ConvParams& q, int scale) {
+        if (!mo.on()) return;
+        q.mos_py = (mo.wh + 1) * scale; q.mos_ry = mo.wh * scale; q.mos_px = (mo.ww + 1) * scale; q.mos_rx = mo.ww * scale;
+        q.mos_kx = mo.kx; q.mos_ky = mo.ky; q.mos_count = mo.count;
+    };
     ConvParams b{};
     b.N = n; b.H = H; b.W = W; b.Hp = w.Hp; b.Wp = w.Wp; b.sHp = w.Hp; b.sWp = w.Wp;
     b.T = w.T; b.R = w.R; b.F = w.F;
+    mosaic_at(b, 1);
     int ci = 0, rc;
     const bool fp8 = w.fp8;
     {   // conv_first: 3 -> 64 (input = one 16-channel block)
@@ -482,6 +500,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
         p.N = n; p.H = 2 * H; p.W = 2 * W; p.Hp = w.Hp2; p.Wp = w.Wp2; p.sHp = w.Hp; p.sWp = w.Wp;
         p.src = w.U0; p.src_img = 4 * w.blk1; p.dst = w.U1; p.dst_img = 4 * w.blk2;
         if (hp) { p.src_lo = w.U0lo; p.lo_img = 4 * w.blk1; p.T = w.U1lo; }
+        mosaic_at(p, h->convs[ci].d_wphase[0] ? 1 : 2);          // sub-pixel form: the epilogue walks SOURCE pixels
         if (h->convs[ci].d_wphase[0]) {
             if ((rc = run_up_subpixel(h, st, h->convs[ci++], p, n, H, W, w.Hp, w.Wp, w.Hp2, w.Wp2))) return rc;
         } else if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
@@ -491,12 +510,14 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
         p.N = n; p.H = 4 * H; p.W = 4 * W; p.Hp = w.Hp4; p.Wp = w.Wp4; p.sHp = w.Hp2; p.sWp = w.Wp2;
         p.src = w.U1; p.src_img = 4 * w.blk2; p.dst = w.U2; p.dst_img = 4 * w.blk4;
         if (hp) { p.src_lo = w.U1lo; p.lo_img = 4 * w.blk2; p.T = w.U2lo; }
+        mosaic_at(p, h->convs[ci].d_wphase[0] ? 2 : 4);
         if (h->convs[ci].d_wphase[0]) {
             if ((rc = run_up_subpixel(h, st, h->convs[ci++], p, n, 2 * H, 2 * W, w.Hp2, w.Wp2, w.Hp4, w.Wp4))) return rc;
         } else if ((rc = run_conv(h, st, F_UP, h->convs[ci++], p, EPI_LRELU, true, hp))) return rc;
     }
     ConvParams hr{};
     hr.N = n; hr.H = 4 * H; hr.W = 4 * W; hr.Hp = w.Hp4; hr.Wp = w.Wp4; hr.sHp = w.Hp4; hr.sWp = w.Wp4;
+    mosaic_at(hr, 4);
     {
         ConvParams p = hr;
         p.src = w.U2; p.src_img = 4 * w.blk4; p.dst = w.U3; p.dst_img = 4 * w.blk4;
@@ -525,36 +546,73 @@ int group_size(const s2sr_handle* h, int B, int H, int W) {
     return g < 1 ? 1 : g;
 }
 
+// Window mosaics: when the tiles are not a multiple of the 32-pixel patch (the reference's 276 x 276 windows: 288 x 288 of patch
+// area each, 9 % dead MFMA work) and there are several of them, kx x ky windows share one image with a zero row / column
+// between neighbours (ConvParams::mos_*): 4 x 4 windows of 276 -> 1107 x 1107 -> 1120 x 1120 of patch area, 280 per window.
+// Same bytes out: every output pixel accumulates the same products in the same order wherever its window sits.
+Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) {
+    Mosaic m;
+    if (!h->mosaic_on || B < 2) return m;
+    const double waste = (double)roundup32(th) * roundup32(tw) / ((double)th * tw);
+    if (waste < 1.03) return m;                       // 256 x 256 tiles and friends: nothing to gain
+    auto side = [](int win, int want) {               // windows per mosaic side: at most 8, mosaic at most ~1280 px (workspace: 4x tensors)
+        int k = 1280 / (win + 1);
+        if (k > 8) k = 8;
+        if (k < 1) k = 1;
+        return k < want ? k : want;
+    };
+    m.kx = side(tw, B);
+    m.ky = side(th, (B + m.kx - 1) / m.kx);
+    if (m.kx * m.ky < 2) return Mosaic();
+    // does it pay?  patch area per window with and without
+    const double a0 = (double)roundup32(th) * roundup32(tw);
+    const double a1 = (double)roundup32(m.ky * (th + 1) - 1) * roundup32(m.kx * (tw + 1) - 1) / (m.kx * m.ky);
+    if (a1 > 0.98 * a0) return Mosaic();
+    m.wh = th; m.ww = tw; m.count = B;
+    return m;
+}
+
 // [B,th,tw,3] u8 (device) -> u8 [B,4th,4tw,3] and/or f32 [B,3,4th,4tw] (device)
 int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const float* d_x_f32, int B, int th, int tw,
                 uint8_t* d_out_u8, float* d_out_f32) {
     if (!h->has_weights) return fail(h, S2SR_E_NOWEIGHTS, "s2sr_load_weights has not been called");
     if (B <= 0 || th <= 0 || tw <= 0) return fail(h, S2SR_E_INVALID, "bad batch/tile dims");
-    const int G = group_size(h, B, th, tw);
-    int rc = ensure_workspace(h, G, th, tw);
+    // u8 tiles may travel as window mosaics; "images" below are then mosaics of per = kx*ky windows
+    const Mosaic mo = d_tiles ? pick_mosaic(h, B, th, tw) : Mosaic();
+    const int per = mo.on() ? mo.kx * mo.ky : 1;
+    const int NI = (B + per - 1) / per;                                       // images to push through the net
+    const int IH = mo.on() ? mo.ky * (th + 1) - 1 : th, IW = mo.on() ? mo.kx * (tw + 1) - 1 : tw;
+    const int G = group_size(h, NI, IH, IW);
+    int rc = ensure_workspace(h, G, IH, IW, mo.on() ? th + 1 : 0, mo.on() ? tw + 1 : 0);
     if (rc) return rc;
     Workspace& w = h->ws;
     const size_t opx = (size_t)16 * th * tw;
-    for (int g0 = 0; g0 < B; g0 += G) {
-        const int n = (B - g0 < G) ? (B - g0) : G;
-        const uint8_t* in8 = d_tiles ? d_tiles + (size_t)g0 * th * tw * 3 : nullptr;
-        const float* in32 = d_tiles ? nullptr : d_x_f32 + (size_t)g0 * 3 * th * tw;
-        float* o32 = d_out_f32 ? d_out_f32 + (size_t)g0 * 3 * opx : nullptr;
-        uint8_t* o8 = d_out_u8 ? d_out_u8 + (size_t)g0 * 3 * opx : nullptr;
+    for (int g0 = 0; g0 < NI; g0 += G) {
+        const int n = (NI - g0 < G) ? (NI - g0) : G;
+        const int t0 = g0 * per;                                              // first window / tile of this group
+        const int nt = (B - t0 < n * per) ? (B - t0) : n * per;               // windows / tiles in it
+        const uint8_t* in8 = d_tiles ? d_tiles + (size_t)t0 * th * tw * 3 : nullptr;
+        const float* in32 = d_tiles ? nullptr : d_x_f32 + (size_t)t0 * 3 * th * tw;
+        float* o32 = d_out_f32 ? d_out_f32 + (size_t)t0 * 3 * opx : nullptr;
+        uint8_t* o8 = d_out_u8 ? d_out_u8 + (size_t)t0 * 3 * opx : nullptr;
+        Mosaic mg = mo;
+        mg.count = nt;
         auto enqueue = [&]() -> int {
             {
-                Scope sc(h, st, F_PACK, 0.0, (double)n * th * tw * (3.0 + 8.0));
-                if (in8) HIPCHK(h, launch_pack_u8(in8, n, th, tw, w.P0, w.Hp, w.Wp, st));
+                Scope sc(h, st, F_PACK, 0.0, (double)nt * th * tw * (3.0 + 8.0));
+                if (in8 && mo.on()) HIPCHK(h, launch_pack_u8_mosaic(in8, nt, th, tw, mo.kx, mo.ky, w.P0, w.Hp, w.Wp, st));
+                else if (in8) HIPCHK(h, launch_pack_u8(in8, n, th, tw, w.P0, w.Hp, w.Wp, st));
                 else HIPCHK(h, launch_pack_f32_nchw(in32, n, 3, th, tw, 255.0f, w.P0, 1, w.Hp, w.Wp, st));
             }
-            return run_net(h, st, n, th, tw, o32, o8);
+            return run_net(h, st, n, IH, IW, o32, o8, mo.on() ? mg : Mosaic());
         };
         // the legacy null stream cannot be captured; profiling wants its events between launches
         GraphEntry* ge = nullptr;
         if (h->graphs_on && h->prof <= 0 && st != nullptr) {
             for (GraphEntry& g : h->graphs)
                 if (g.n == n && g.th == th && g.tw == tw && g.in_u8 == in8 && g.in_f32 == in32 && g.out_u8 == o8 &&
-                    g.out_f32 == o32 && g.st == st) { ge = &g; break; }
+                    g.out_f32 == o32 && g.st == st && g.mos_kx == (mo.on() ? mo.kx : 0) && g.mos_ky == (mo.on() ? mo.ky : 0) &&
+                    g.mos_count == (mo.on() ? nt : 0)) { ge = &g; break; }
             if (!ge) {   // first sighting: remember it, launch directly (also warms the per-kernel attributes)
                 if (h->graphs.size() >= 16) {
                     size_t victim = 0;
@@ -565,6 +623,7 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
                 }
                 GraphEntry g;
                 g.n = n; g.th = th; g.tw = tw; g.in_u8 = in8; g.in_f32 = in32; g.out_u8 = o8; g.out_f32 = o32; g.st = st;
+                g.mos_kx = mo.on() ? mo.kx : 0; g.mos_ky = mo.on() ? mo.ky : 0; g.mos_count = mo.on() ? nt : 0;
                 g.last_use = ++h->graph_clock;
                 h->graphs.push_back(g);
                 ge = nullptr;
@@ -654,6 +713,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     }
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_MOSAIC")) h->mosaic_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
@@ -1437,7 +1497,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0;
     return S2SR_OK;
 }
 

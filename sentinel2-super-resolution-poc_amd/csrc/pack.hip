@@ -38,6 +38,34 @@ hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk
     return hipGetLastError();
 }
 
+__global__ void pack_u8_mosaic_kernel(const uint8_t* __restrict__ in, int B, int h, int w, int kx, int ky, char* __restrict__ blk, int Hp,
+                                      int Wp) {
+    const size_t total = (size_t)B * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lx = (int)(i % w);
+        const size_t r = i / w;
+        const int ly = (int)(r % h);
+        const int t = (int)(r / h);
+        const int n = t / (kx * ky), slot = t - n * (kx * ky);
+        const int wy = slot / kx, wx = slot - wy * kx;
+        const int y = wy * (h + 1) + ly, x = wx * (w + 1) + lx;
+        const uint8_t* s = in + i * 3;
+        f16x4 v;
+        v[0] = (f16)(float)s[0];
+        v[1] = (f16)(float)s[1];
+        v[2] = (f16)(float)s[2];
+        v[3] = (f16)0.f;
+        *(f16x4*)(blk + (((size_t)n * Hp + y + 1) * Wp + x + 1) * 32) = v;
+    }
+}
+
+hipError_t launch_pack_u8_mosaic(const uint8_t* d_tiles, int B, int h, int w, int kx, int ky, char* blk, int Hp, int Wp, hipStream_t st) {
+    const size_t total = (size_t)B * h * w;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_u8_mosaic_kernel, dim3(grid), dim3(256), 0, st, d_tiles, B, h, w, kx, ky, blk, Hp, Wp);
+    return hipGetLastError();
+}
+
 __global__ void pack_f32_nchw_kernel(const float* __restrict__ x, int N, int C, int H, int W, float scale,
                                      char* __restrict__ blk, int NB, int Hp, int Wp) {
     const size_t total = (size_t)N * C * H * W;

@@ -86,11 +86,26 @@ struct ConvParams {
     int32_t f8_form;         // conv_trunk_f8 conv1-4 kernel form (diagnostics): bit 0 no loader wave, bits 1-2 weight placement (0 default, 1 all
                              // streamed, 2 all resident), bit 3 two waves per SIMD -- from S2SR_FP8_LOADER / _WSTREAM / _W8 at s2sr_create
     int32_t lo_exp;          // conv_trunk_f16 conv5: the trunk's lo half is stored as e4m3(lo * 2^lo_exp) planes (xh_in, T, lo_skip)
+    // Window mosaics (the AOI path, engine.hip forward_dev): equal-size windows of `_tile_process` (cnn_super_resolution.py:249-257) laid
+    // out on a grid inside ONE image with a single zero row / column between neighbours -- the conv zero padding of both, at
+    // every layer, because no launch ever stores to a separator pixel: at the scale of the coordinates the epilogue works in,
+    // (y, x) is live iff y % mos_py < mos_ry and x % mos_px < mos_rx (period = window + 1, real extent = window).  0 = off.
+    // 276-pixel windows then cost 280 x 280 of patch area instead of 288 x 288.
+    int32_t mos_py, mos_ry, mos_px, mos_rx;
+    int32_t mos_kx, mos_ky, mos_count;   // EPI_LAST: grid of a mosaic and the number of windows in this launch: window t = (n * ky + wy) * kx + wx
+                                         // is written as image t of [count, ry, rx]; slots past the count are not written
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
     unsigned long long* trace;   // diagnostic build only: s_memtime stamps, 24 per workgroup
     int32_t dbg;                 // diagnostic only (timing ablations, results wrong): 1 weights DMA from one fixed piece,
                                  // 2 slab DMA from one fixed piece, 4 per-wave stamps, 8 no DMA instructions in the loop
 };
+
+// is output pixel (y, x) of this launch one the reference writes (inside the image, and not a mosaic separator)?
+__device__ __forceinline__ bool px_live(const ConvParams& p, int y, int x) {
+    bool ok = (y < p.H) && (x < p.W);
+    if (p.mos_py) ok = ok && (y % p.mos_py < p.mos_ry) && (x % p.mos_px < p.mos_rx);
+    return ok;
+}
 
 // conv kernel (conv3x3.hip).  ct = ceil(Cout/32) in {1,2}.
 hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool lo_out, hipStream_t st, bool f8_in = false);
@@ -144,6 +159,9 @@ hipError_t launch_tiles_overview(const uint8_t* d_child, int cnx, int cny, int o
 
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);
+// the same for a window mosaic: B windows of h x w into ceil(B / (kx*ky)) images of (ky*(h+1)-1) x (kx*(w+1)-1), window t at grid
+// cell (t % (kx*ky)) / kx, % kx of image t / (kx*ky); separator rows / columns are never written
+hipError_t launch_pack_u8_mosaic(const uint8_t* d_tiles, int B, int h, int w, int kx, int ky, char* blk, int Hp, int Wp, hipStream_t st);
 hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, float scale, char* blk, int NB,
                                 int Hp, int Wp, hipStream_t st);
 hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int lo_e4m3_exp, int N, int Hp, int Wp, char* out,

@@ -395,7 +395,9 @@ def _debug_config(self) -> dict:
     """What s2sr_create read from the environment for this handle (kernel forms, scales)."""
     c = DebugConfig()
     self._check(self._lib.s2sr_debug_get_config(self._h, C.byref(c)), "s2sr_debug_get_config")
-    return {n: int(getattr(c, n)) for n, _ in DebugConfig._fields_ if n != "reserved"}
+    d = {n: int(getattr(c, n)) for n, _ in DebugConfig._fields_ if n != "reserved"}
+    d["mosaic_on"] = int(c.reserved[0])
+    return d
 
 
 def _debug_conv_trunk(self, kind, x, weight, bias, lo=None, skip=None, form=0):

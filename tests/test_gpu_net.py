@@ -28,7 +28,7 @@ TOL_FP8_6 = 1e-3
 _ENG = {}
 
 
-_SWITCHES = ("S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
+_SWITCHES = ("S2SR_MOSAIC", "S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
              "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH")
 
 
@@ -519,6 +519,36 @@ def test_row_winograd_trunk_goldens(monkeypatch, golden_dir):
     print(f"row-Winograd trunk, 256x256 tile vs the oracle: float max-abs {err:.3e}, u8 identical {np.mean(dq == 0):.4f}")
     assert err <= TOL_HP and dq.max() <= 1 and np.mean(dq == 0) > 0.99
     e.close()
+
+
+@pytest.mark.parametrize("prec", [native.PREC_F16_HP, native.PREC_F16, native.PREC_FP8])
+def test_window_mosaics_give_the_same_bytes(monkeypatch, prec):
+    """Windows that are no multiple of the 32-pixel patch (the reference's 276 x 276) travel as MOSAICS: kx x ky windows in one
+    image with a zero row / column between neighbours, never stored to (ConvParams::mos_*; 280 x 280 instead of 288 x 288 of
+    patch area per window).  Every output pixel accumulates the same products in the same order wherever its window sits,
+    so the bytes must equal those of one-window-per-image processing (S2SR_MOSAIC=0, a fresh handle), for batches that
+    fill their mosaics, ragged ones, single windows, the u8 and the float output, and through enhance()'s banded path."""
+    nb = 2
+    rng = np.random.default_rng(17)
+    on = _fresh(monkeypatch, nb, prec, {})
+    off = _fresh(monkeypatch, nb, prec, {"S2SR_MOSAIC": "0"})
+    assert on.debug_config()["mosaic_on"] == 1 and off.debug_config()["mosaic_on"] == 0
+    for (B, h, w) in [(16, 84, 84), (5, 24, 40), (7, 50, 33), (2, 276, 276), (1, 84, 84), (20, 37, 45)]:
+        tiles = rng.integers(0, 256, size=(B, h, w, 3), dtype=np.uint8)
+        a, b = on.forward_batch_u8(tiles), off.forward_batch_u8(tiles)
+        assert np.array_equal(a, b), (B, h, w, int(np.abs(a.astype(int) - b.astype(int)).max()))
+        assert np.array_equal(on.forward_batch_u8(tiles), a)                       # replay (hipGraph) and stale-slot hygiene
+    for (H, W, ts, tp) in [(300, 290, 64, 10), (150, 170, 64, 10), (100, 90, 16, 2)]:
+        img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        assert np.array_equal(on.enhance_u8(img, tile=ts, pad=tp), off.enhance_u8(img, tile=ts, pad=tp)), (H, W)
+        assert np.array_equal(on.enhance_f32(img, tile=ts, pad=tp), off.enhance_f32(img, tile=ts, pad=tp)), (H, W)
+    # a plain batch after mosaics and back (workspace turnover: separators must come from a fresh memset)
+    t256 = rng.integers(0, 256, size=(2, 64, 64, 3), dtype=np.uint8)
+    t84 = rng.integers(0, 256, size=(4, 84, 84, 3), dtype=np.uint8)
+    r256, r84 = off.forward_batch_u8(t256), off.forward_batch_u8(t84)
+    for _ in range(2):
+        assert np.array_equal(on.forward_batch_u8(t256), r256) and np.array_equal(on.forward_batch_u8(t84), r84)
+    on.close(); off.close()
 
 
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
