@@ -405,10 +405,11 @@ def main():
         # 256/10 window plan = 256 windows of 276x276), seed 4321
         aoi_n = 4096
         aoi = np.random.Generator(np.random.PCG64(4321)).integers(0, 256, size=(aoi_n, aoi_n, 3), dtype=np.uint8)
-        eng.enhance_u8(aoi[:1024, :1024])           # warm-up: workspace for 276x276 windows, graphs
-        eng.enhance_u8(aoi)
+        eng.enhance_u8(aoi[:1024, :1024])           # warm-up: workspace for the window mosaics
+        eng.enhance_u8(aoi)                         # first sighting of each chunk: direct launches
+        eng.enhance_u8(aoi)                         # second sighting: each chunk's hipGraph is captured
         t0 = time.perf_counter()
-        out = eng.enhance_u8(aoi)
+        out = eng.enhance_u8(aoi)                   # steady state: graph replays
         dta = time.perf_counter() - t0
         nwin = len(native.plan_tiles(aoi_n, aoi_n, 256, 10))
         sec["aoi"] = {"value": round(16 * aoi_n * aoi_n / 1e6 / dta, 1), "unit": "SR-MP/s", "seconds": round(dta, 3),
