@@ -90,3 +90,75 @@ def test_more_published_known_answers():
     # the Lab L axis: L* = 116 (Y/Yn)^(1/3) - 16 scaled by 255/100; mid gray 128 -> Y = 0.2158 -> L* = 53.585 -> 136.6 -> 137
     lab = pp.rgb2lab_u8(np.array([[[128, 128, 128], [255, 255, 255], [0, 0, 0]]], np.uint8))[0].tolist()
     assert lab[1] == [255, 128, 128] and lab[2] == [0, 128, 128] and lab[0][1:] == [128, 128] and abs(lab[0][0] - 137) <= 1
+
+
+def test_clahe_constant_plane_closed_form():
+    """OpenCV's CLAHE on a CONSTANT plane has a closed form that needs no image: every tile's histogram is one spike of
+    `area` counts at v; it is clipped to `clip = max(1, int(clipLimit * area / 256))`, the excess is spread as
+    `excess // 256` to every bin plus one more to bins 0, step, 2*step, ... (step = max(256 // residual, 1)) while the
+    residual lasts; lut[i] = saturate(cvRound(cdf[i] * 255 / area)).  All tiles share that LUT, so the interpolation
+    returns lut[v] everywhere.  (clahe.cpp: CLAHE_CalcLut_Body; this pins the clip / redistribution / LUT-scale reading
+    of the oracle independently of its code.)"""
+    for (H, W, clip_limit, grid) in ((64, 64, 2.5, 8), (128, 96, 2.5, 8), (1024, 1024, 2.5, 8), (72, 72, 3.0, 8), (64, 64, 40.0, 8)):
+        th, tw = H // grid, W // grid
+        area = th * tw
+        clip = max(int(clip_limit * area / 256), 1)
+        for v in (0, 1, 77, 128, 254, 255):
+            hist = np.zeros(256, np.int64)
+            hist[v] = min(area, clip)
+            excess = area - hist[v]
+            hist += excess // 256
+            residual = excess - (excess // 256) * 256
+            if residual:
+                step = max(256 // residual, 1)
+                idx = np.arange(0, 256, step)[:residual]
+                hist[idx] += 1
+            lut_v = int(np.clip(np.rint(np.float32(hist[:v + 1].sum()) * (np.float32(255.0) / np.float32(area))), 0, 255))
+            out = pp.clahe_u8(np.full((H, W), v, np.uint8), clip_limit, grid)
+            assert np.all(out == lut_v), (H, W, clip_limit, v, int(out[0, 0]), lut_v)
+    # at the wow / farm setting (2.5, 8x8) on a 1024^2 plane: tile area 16384, clip 160 -> lut[v] = round((v+1)*63.375*255/16384 + 160*255/16384)
+    out = pp.clahe_u8(np.full((1024, 1024), 100, np.uint8), 2.5, 8)
+    assert int(out[0, 0]) == int(np.rint((160 + 101 * 63 + len(np.arange(0, 256, 256 // 96)[:96][np.arange(0, 256, 256 // 96)[:96] <= 100])) * 255.0 / 16384))
+
+
+def test_gaussian_fixed_point_taps_are_pinned():
+    """The 8-bit GaussianBlur path uses 8.8 fixed-point taps that sum to exactly 256.  The float kernel follows from the
+    documented getGaussianKernel formula exp(-x^2 / (2 sigma^2)) / sum; the integer taps must each lie within one unit of
+    256 * w and be symmetric, non-increasing from the centre, and the literal values this oracle (and the HIP kernel) use
+    are written out here so that a future cv2 golden that disagrees points at THIS line."""
+    want = {1.2: [0, 4, 21, 60, 86, 60, 21, 4, 0], 1.5: [0, 2, 9, 28, 55, 68, 55, 28, 9, 2, 0], 1.0: [1, 14, 62, 102, 62, 14, 1]}
+    for sigma, taps in want.items():
+        t = pp.gaussian_kernel_q8(sigma)
+        n = int(np.rint(sigma * 6 + 1)) | 1
+        x = np.arange(n) - (n - 1) / 2
+        w = np.exp(-x * x / (2 * sigma * sigma))
+        w = w / w.sum() * 256.0
+        assert len(t) == n and t.sum() == 256 and np.array_equal(t, t[::-1])
+        assert np.all(np.abs(t - w) <= 1.0), (sigma, t.tolist(), w.round(2).tolist())
+        assert np.all(np.diff(t[: n // 2 + 1]) >= 0)
+        assert t.tolist() == taps, (sigma, t.tolist())
+
+
+def test_add_weighted_tie_cases_are_enumerated():
+    """cv2.addWeighted on 8U computes a*alpha + b*beta in float and rounds half to even (cvRound).  Where that float sum is
+    EXACTLY x.5 the result depends on the rounding mode and on whether the implementation rounds the products first (SIMD
+    v_fma forms) -- these are the pixels a future cv2 golden has to look at first.  For the reference's weights
+    (1.4, -0.4: wow_sr.py:197; 2.2, -1.2: farm_sr.py:69) no (a, b) in [0,255]^2 is an exact tie in float32 (1.4f and 0.4f are
+    not dyadic), so the rounding mode cannot matter there; with dyadic weights ties exist and must go to the even neighbour."""
+    a, b = np.meshgrid(np.arange(256, dtype=np.float32), np.arange(256, dtype=np.float32), indexing="ij")
+    for alpha, beta in ((1.4, -0.4), (2.2, -1.2)):
+        r = a * np.float32(alpha) + b * np.float32(beta)
+        ties = np.abs(r - np.floor(r) - np.float32(0.5)) == 0
+        assert ties.sum() == 0, (alpha, beta, int(ties.sum()))
+        # nearest misses: how close any pair comes to a tie (what a float64 / fused implementation could flip)
+        near = np.abs(r - np.floor(r) - 0.5).min()
+        assert near > 1e-6
+        # a float64 evaluation of the same weights agrees everywhere after rounding: no pixel of this stage is rounding-mode dependent
+        r64 = a.astype(np.float64) * alpha + b.astype(np.float64) * beta
+        assert np.array_equal(np.clip(np.rint(r), 0, 255), np.clip(np.rint(r64), 0, 255))
+    r = a * np.float32(1.5) + b * np.float32(-0.5)
+    ties = (r - np.floor(r)) == 0.5
+    assert ties.sum() > 1000
+    got = pp.add_weighted_u8(a.astype(np.uint8), 1.5, b.astype(np.uint8), -0.5)
+    exp = np.clip(np.where(ties, 2 * np.round(r / 2), np.rint(r)), 0, 255).astype(np.uint8)   # ties -> even
+    assert np.array_equal(got, exp)
