@@ -58,6 +58,9 @@
                            // registers fit the 256): the epilogue reads them in place, 128 v_accvgpr_read per patch and wave less.  Same bytes out;
                            // measured (tools/ab_macro.sh, A/B/A/B on one box) conv1-4 73.4 -> 72.0 us per launch, step 85.9 -> 85.4 ms
 #endif
+#ifndef S2SR_F16_LOENC
+#define S2SR_F16_LOENC 1   // conv_trunk_f16 conv5: the short form of the lo encoding (v_fma_mix_f32 + v_cvt_scalef32_pk_fp8_f32), see the epilogue
+#endif
 #ifndef S2SR_F16_PULL
 #define S2SR_F16_PULL 0         // conv_trunk_f16 conv5: 1 = the DMA quota of a patch's first stage is issued inside the previous patch's epilogue
                                 // (the slot is free by then), so the ring does not run down while the wave converts and stores.  Measured
@@ -566,6 +569,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         }
         const size_t ln = (size_t)n * 2 * oblk;   // image offset inside the e4m3 lo tensors, bytes
         const float lo_dec = __builtin_ldexpf(1.0f, -p.lo_exp), lo_enc = __builtin_ldexpf(1.0f, p.lo_exp);   // e4m3 lo planes hold lo * 2^lo_exp
+        const float lo_lim = __builtin_ldexpf(448.0f, -p.lo_exp);                                            // ... of |lo| up to 448 * 2^-lo_exp
+        (void)lo_enc; (void)lo_lim;
         // the four dwords of a lane's channel groups out of the 16 bytes it fetched (q[g] = channels 8g+4hh.. of the plane)
         auto unswap = [&](const f32x4& o, uint32_t (&q)[4]) __attribute__((always_inline)) {
             const u32x4 u = __builtin_bit_cast(u32x4, o);
@@ -680,6 +685,26 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         // (plain C++ on purpose: the same arithmetic as fma(fp16(v), -2^lo_exp, v * 2^lo_exp) through an asm v_fma_mix_f32
                         // is bit-identical in isolation -- tools/scratch/mix_test.hip -- but inside this kernel measured 1.4e-3 on the
                         // stress net instead of 1.3e-4, for a reason not found; not worth 100 instructions per patch)
+#if S2SR_F16_LOENC
+                        // r03: 2.5 instead of 4.5 instructions per value (the conv5 epilogue was 1/3 lo encoding): v - fp16(v) in ONE
+                        // v_fma_mix_f32 that reads the packed half in place (exact: the difference of a float and its own fp16 rounding),
+                        // the clamp on the unscaled value, and the 2^lo_exp inside v_cvt_scalef32_pk_fp8_f32 (it divides by the power
+                        // of two of its scale operand and, like the plain conversion, turns overflow into NaN -- hence the clamp:
+                        // tools/micro/cvt_scale_probe.hip).  Same bytes as the long form.
+                        float q[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float d;
+                            if (i & 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk[g][i >> 1]), "v"(v[i]));
+                            else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk[g][i >> 1]), "v"(v[i]));
+                            q[i] = S2SR_DIAG_NOLO ? 0.0f : __builtin_amdgcn_fmed3f(d, -lo_lim, lo_lim);
+                        }
+                        typedef short v2s __attribute__((ext_vector_type(2)));
+                        v2s w8 = {0, 0};
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[0], q[1], lo_dec, false);
+                        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[2], q[3], lo_dec, true);
+                        lq8[g] = __builtin_bit_cast(uint32_t, w8);
+#else
                         float q[4];
                         {
                             const f16x4 hv4 = __builtin_bit_cast(f16x4, hpk[g]);
@@ -690,6 +715,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                         int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
                         w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w8, true);
                         lq8[g] = (uint32_t)w8;
+#endif
                     }
                 }
                 // pair the half-waves: one 16-B store per 16-channel block, 1 KiB contiguous per wave-instruction
