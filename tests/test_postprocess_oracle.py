@@ -162,3 +162,82 @@ def test_add_weighted_tie_cases_are_enumerated():
     got = pp.add_weighted_u8(a.astype(np.uint8), 1.5, b.astype(np.uint8), -0.5)
     exp = np.clip(np.where(ties, 2 * np.round(r / 2), np.rint(r)), 0, 255).astype(np.uint8)   # ties -> even
     assert np.array_equal(got, exp)
+
+
+def test_colour_conversions_track_their_float_definitions():
+    """Independent of OpenCV's fixed-point tables: the 8-bit conversions of the oracle must stay within a small bound of
+    the DEFINITIONS OpenCV documents for them (cvtColor docs), evaluated in float64 -- sRGB -> linear (IEC 61966-2-1) ->
+    XYZ (D65) -> CIE L*a*b*, 8-bit encoding L*255/100, a+128, b+128; HSV with H in [0,180).  OpenCV's own 8-bit path is a
+    fixed-point approximation of the same definitions (documented error <= 2 LSB-ish), so a restatement that drifts
+    further than that is wrong whatever cv2 would say.  200k random colours + the cube's corners and the gray axis."""
+    import colorsys
+    rng = np.random.default_rng(11)
+    cols = rng.integers(0, 256, size=(200_000, 3), dtype=np.uint8)
+    corners = np.array([[r, g, b] for r in (0, 255) for g in (0, 255) for b in (0, 255)], np.uint8)
+    gray = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, axis=1)
+    cols = np.concatenate([cols, corners, gray])[None]
+    # --- Lab
+    c = cols[0].astype(np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    xyz = lin @ M.T
+    xyz[:, 0] /= 0.950456
+    xyz[:, 2] /= 1.088754
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    L = np.where(xyz[:, 1] > 0.008856, 116.0 * np.cbrt(xyz[:, 1]) - 16.0, 903.3 * xyz[:, 1])
+    a = 500.0 * (f[:, 0] - f[:, 1])
+    b = 200.0 * (f[:, 1] - f[:, 2])
+    want = np.stack([L * 255.0 / 100.0, a + 128.0, b + 128.0], axis=1)
+    got = pp.rgb2lab_u8(cols)[0].astype(np.float64)
+    d = np.abs(got - np.clip(want, 0, 255))
+    # the fixed-point gamma / cube-root tables are coarse where the curves are steep: a few colours (dark ones mostly, e.g. RGB (1, 9, 57))
+    # deviate by up to 2.4 in a / b; 99.5 % of colours are the rounded float value
+    assert d.max() <= 3.0, (float(d.max()), cols[0][np.unravel_index(d.argmax(), d.shape)[0]].tolist())
+    assert (d <= 0.75).mean() > 0.99 and (d <= 1.5).mean() > 0.9995, (float((d <= 0.75).mean()), float((d <= 1.5).mean()))
+    # and back: Lab2RGB of an 8-bit Lab triple against the float inverse of the SAME triple (the round trip itself is lossy by up
+    # to ~25 levels for saturated dark colours: 8-bit a / b quantisation, not an implementation matter)
+    lab8 = pp.rgb2lab_u8(cols)
+    l8 = lab8[0].astype(np.float64)
+    Ls, as_, bs = l8[:, 0] * 100.0 / 255.0, l8[:, 1] - 128.0, l8[:, 2] - 128.0
+    fy = (Ls + 16.0) / 116.0
+    Y = np.where(Ls > 903.3 * 0.008856, fy ** 3, Ls / 903.3)
+    fy = np.where(Y > 0.008856, np.cbrt(Y), 7.787 * Y + 16.0 / 116.0)
+    fx, fz = fy + as_ / 500.0, fy - bs / 200.0
+    inv = lambda t: np.where(t > 6.0 / 29.0, t ** 3, (t - 16.0 / 116.0) / 7.787)
+    X, Z = inv(fx) * 0.950456, inv(fz) * 1.088754
+    lin2 = np.stack([X, Y, Z], axis=1) @ np.linalg.inv(M).T
+    lin2 = np.clip(lin2, 0.0, 1.0)
+    srgb = np.where(lin2 <= 0.0031308, 12.92 * lin2, 1.055 * lin2 ** (1 / 2.4) - 0.055) * 255.0
+    back = pp.lab2rgb_u8(lab8)[0].astype(np.float64)
+    e = np.abs(back - np.clip(srgb, 0, 255))
+    assert (e <= 1.0).mean() > 0.99 and e.max() <= 4.0, (float(e.max()), float((e <= 1.0).mean()))
+    # --- HSV
+    hsv = pp.rgb2hsv_u8(cols)[0].astype(np.float64)
+    cf = cols[0].astype(np.float64)
+    V = cf.max(axis=1)
+    mn = cf.min(axis=1)
+    S = np.where(V > 0, 255.0 * (V - mn) / np.maximum(V, 1), 0.0)
+    assert np.array_equal(hsv[:, 2], V) and np.abs(hsv[:, 1] - S).max() <= 0.6
+    hh = np.array([colorsys.rgb_to_hsv(*(px / 255.0))[0] * 180.0 for px in cf[:20000]])
+    dh = np.abs(hsv[:20000, 0] - hh)
+    dh = np.minimum(dh, 180.0 - dh)
+    sat = (V[:20000] - mn[:20000]) > 0
+    assert dh[sat].max() <= 0.75, float(dh[sat].max())     # 12-bit reciprocal tables: up to ~0.6 of a level from the exact hue
+
+
+def test_gaussian_blur_tracks_the_float_definition():
+    """The fixed-point blur against scipy's float Gaussian with the same support (ksize = cvRound(6 sigma + 1) | 1) and
+    BORDER_REFLECT_101 (scipy mode='mirror'): within 1 LSB everywhere."""
+    from scipy import ndimage
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, size=(61, 83, 3), dtype=np.uint8)
+    for sigma in (1.2, 1.5):
+        n = int(np.rint(sigma * 6 + 1)) | 1
+        x = np.arange(n) - (n - 1) / 2
+        k = np.exp(-x * x / (2 * sigma * sigma))
+        k /= k.sum()
+        ref = img.astype(np.float64)
+        ref = ndimage.correlate1d(ref, k, axis=0, mode="mirror")
+        ref = ndimage.correlate1d(ref, k, axis=1, mode="mirror")
+        d = np.abs(pp.gaussian_blur_u8(img, sigma).astype(np.float64) - ref)
+        assert d.max() <= 1.0, (sigma, float(d.max()))
