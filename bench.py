@@ -404,7 +404,7 @@ def main():
         # AOI mosaic through the reference's entry point (s2sr_enhance_u8: host image in, host image out, the reference's
         # 256/10 window plan = 256 windows of 276x276), seed 4321
         aoi_n = 4096
-        aoi = np.random.Generator(np.random.PCG64(4321)).integers(0, 256, size=(aoi_n, aoi_n, 3), dtype=np.uint8)
+        aoi = synthetic_tiles(1, aoi_n, seed=4321)[0]          # the tile bench's generator (image-like statistics), seed 4321: SURVEY.md 8d
         eng.enhance_u8(aoi[:1024, :1024])           # warm-up: workspace for the window mosaics
         eng.enhance_u8(aoi)                         # first sighting of each chunk: direct launches
         eng.enhance_u8(aoi)                         # second sighting: each chunk's hipGraph is captured

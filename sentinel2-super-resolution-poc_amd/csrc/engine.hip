@@ -537,11 +537,11 @@ int group_size(const s2sr_handle* h, int B, int H, int W) {
     // default group: 16 images per launch sequence; the fp8 trunk's launches are half as long, so it takes 32 (measured:
     // 50.5 vs 51.9 ms per 32-tile step; the fp16 modes gain nothing from 32)
     int g = h->cfg.group > 0 ? h->cfg.group : (h->cfg.precision == S2SR_PREC_FP8 ? 32 : 16);
-    // keep the workspace within a quarter of the 288 GB: bytes per LR pixel 32 + 3*384 (dense) + 128 + 3*128 (lo) + 2*256
+    // keep the workspace within a third of the 288 GB: bytes per LR pixel 32 + 3*384 (dense) + 128 + 3*128 (lo) + 2*256
     // (fp32 skips) + 2*128 (hp planes); 2x and 4x tensors with their correction planes
     const double per_img = (double)padded(H) * padded(W) * 2500.0 + (double)padded(2 * H) * padded(2 * W) * 256.0 +
                            (double)padded(4 * H) * padded(4 * W) * 512.0;
-    while (g > 1 && per_img * g > 64.0 * 1024 * 1024 * 1024) --g;
+    while (g > 1 && per_img * g > 96.0 * 1024 * 1024 * 1024) --g;
     if (g > B) g = B;
     return g < 1 ? 1 : g;
 }
@@ -1092,15 +1092,27 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, launch_gather_windows((const uint8_t*)h->d_scratch[0], H, W, d_rects, T, wh, ww, (uint8_t*)h->d_scratch[2], st));
-        const int G = group_size(h, T, wh, ww);
+        int G = group_size(h, T, wh, ww);
+        {
+            // windows that travel as mosaics (forward_dev): a chunk should fill whole launch groups of mosaics, and enough of them that
+            // the patch count of a launch is large against the 256 workgroups -- one 4 x 4 mosaic of 276-pixel windows is 1225
+            // patches = 4.8 per CU, i.e. 5 rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24
+            const Mosaic mo = pick_mosaic(h, T, wh, ww);
+            if (mo.on()) {
+                const int per = mo.kx * mo.ky;
+                const int gm = group_size(h, (T + per - 1) / per, mo.ky * (wh + 1) - 1, mo.kx * (ww + 1) - 1);
+                G = gm * per;
+            }
+        }
         if (!out_f32 && T > G) {
             // Big mosaics: whole window rows in chunks of >= G windows.  An output row is final once the
             // last window row that pastes into it is done (the row map is monotone), so each chunk is
             // followed by the stitch of its band of final rows, and the band's device-to-host copy runs
             // on the copy stream under the next chunk's compute.
-            const int rpc = (G + nx - 1) / nx;
+            int rpc = (G + nx - 1) / nx;
             const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
             const int nchunks = (ny + rpc - 1) / rpc;
+            rpc = (ny + nchunks - 1) / nchunks;                   // the same number of chunks, evenly filled (16 rows: 6 + 5 + 5, not 6 + 6 + 4)
             while ((int)h->group_done.size() < nchunks) {
                 hipEvent_t e;
                 HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));

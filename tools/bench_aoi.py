@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """AOI mosaic path (BASELINE configs[2] on one GPU): s2sr_enhance_u8 on host images, window plans
 256/10 (the reference default) and 512/10."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,8 +17,14 @@ e = native.Engine(num_block=23, precision=native.PREC_F16_HP)
 e.load_state_dict(synthetic_state_dict(23, seed=0))
 rng = np.random.default_rng(4321)
 for side in ([int(a) for a in sys.argv[1:]] or [1024, 2048]):
-    img = rng.integers(0, 256, (side, side, 3), dtype=np.uint8)
-    for tile in (256, 512):
+    # S2SR_AOI_IMAGE=noise: white noise (r01 / r02 figures); default: the image-like statistics of the tile bench (s2sr.synth,
+    # same generator, seed 4321) -- MFMA power depends on the data, and the part is power capped
+    if os.environ.get("S2SR_AOI_IMAGE") == "noise":
+        img = rng.integers(0, 256, (side, side, 3), dtype=np.uint8)
+    else:
+        from s2sr.synth import synthetic_tiles
+        img = synthetic_tiles(1, side, seed=4321)[0]
+    for tile in [int(t) for t in os.environ.get("S2SR_AOI_TILES", "256,512").split(",")]:
         nwin = len(native.plan_tiles(side, side, tile, 10))
         e.enhance_u8(img, tile=tile, pad=10)
         e.enhance_u8(img, tile=tile, pad=10)      # second sighting of every chunk: its hipGraph is captured here, not in the timed runs
