@@ -1092,27 +1092,31 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, launch_gather_windows((const uint8_t*)h->d_scratch[0], H, W, d_rects, T, wh, ww, (uint8_t*)h->d_scratch[2], st));
-        int G = group_size(h, T, wh, ww);
+        // Chunks of whole window rows.  An output row is final once the last window row that pastes into it is done (the row
+        // map is monotone), so each chunk is followed by the stitch of its band of final rows, and the band's device-to-host
+        // copy runs on the copy stream under the next chunk's compute.  A chunk holds whole launch groups: for windows that
+        // travel as mosaics (forward_dev) rows in multiples of what fills a mosaic, and as many mosaics as the workspace
+        // allows -- the patch count of a launch must be large against the 256 workgroups (one 4 x 4 mosaic of 276-pixel
+        // windows is 1225 patches = 4.8 per CU, five rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24) -- but at
+        // least three chunks where the image has that many, so that the copies overlap.
+        int rpc = ny, nchunks = 1;
         {
-            // windows that travel as mosaics (forward_dev): a chunk should fill whole launch groups of mosaics, and enough of them that
-            // the patch count of a launch is large against the 256 workgroups -- one 4 x 4 mosaic of 276-pixel windows is 1225
-            // patches = 4.8 per CU, i.e. 5 rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24
             const Mosaic mo = pick_mosaic(h, T, wh, ww);
-            if (mo.on()) {
-                const int per = mo.kx * mo.ky;
-                const int gm = group_size(h, (T + per - 1) / per, mo.ky * (wh + 1) - 1, mo.kx * (ww + 1) - 1);
-                G = gm * per;
-            }
+            const int per = mo.on() ? mo.kx * mo.ky : 1;
+            const int gw = (mo.on() ? group_size(h, (T + per - 1) / per, mo.ky * (wh + 1) - 1, mo.kx * (ww + 1) - 1)
+                                    : group_size(h, T, wh, ww)) * per;                  // windows per launch group
+            const int r_min = (per + nx - 1) / nx;                                      // rows that fill a mosaic
+            const int units = (ny + r_min - 1) / r_min;                                 // ... and how many such row units the image has
+            int u_max = gw / nx / r_min;                                                // units per chunk the workspace allows
+            if (u_max < 1) u_max = 1;
+            nchunks = (units + u_max - 1) / u_max;
+            const int want = units < 3 ? units : 3;
+            if (nchunks < want) nchunks = want;
+            rpc = r_min * ((units + nchunks - 1) / nchunks);                            // evenly filled (16 rows: 6 + 5 + 5, not 6 + 6 + 4)
+            nchunks = (ny + rpc - 1) / rpc;
         }
-        if (!out_f32 && T > G) {
-            // Big mosaics: whole window rows in chunks of >= G windows.  An output row is final once the
-            // last window row that pastes into it is done (the row map is monotone), so each chunk is
-            // followed by the stitch of its band of final rows, and the band's device-to-host copy runs
-            // on the copy stream under the next chunk's compute.
-            int rpc = (G + nx - 1) / nx;
+        if (!out_f32 && nchunks > 1) {
             const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
-            const int nchunks = (ny + rpc - 1) / rpc;
-            rpc = (ny + nchunks - 1) / nchunks;                   // the same number of chunks, evenly filled (16 rows: 6 + 5 + 5, not 6 + 6 + 4)
             while ((int)h->group_done.size() < nchunks) {
                 hipEvent_t e;
                 HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
