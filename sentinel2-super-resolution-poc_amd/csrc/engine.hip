@@ -137,6 +137,7 @@ struct s2sr_handle {
     int trunk_wino = 0;           // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1: all four, 2: conv2-4 only (Cin >= 96)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
+    int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
@@ -562,7 +563,9 @@ Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) {
         return k < want ? k : want;
     };
     m.kx = side(tw, B);
+    if (h->mosaic_kx > 0 && h->mosaic_kx < m.kx) m.kx = h->mosaic_kx;      // S2SR_MOSAIC_KX (diagnostic): narrower mosaics
     m.ky = side(th, (B + m.kx - 1) / m.kx);
+    if (h->mosaic_kx > 0) { const int want = 16 / m.kx; if (want > m.ky && want <= 8 && want * m.kx <= B) m.ky = want; }
     if (m.kx * m.ky < 2) return Mosaic();
     // does it pay?  patch area per window with and without
     const double a0 = (double)roundup32(th) * roundup32(tw);
@@ -714,6 +717,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_MOSAIC")) h->mosaic_on = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_MOSAIC_KX")) h->mosaic_kx = atoi(g);
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
