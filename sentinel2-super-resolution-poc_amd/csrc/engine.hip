@@ -255,7 +255,16 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mo
         oTz = take(g * 4 * w.blk1);
     }
     w.bytes = off;
-    HIPCHK(h, hipMalloc((void**)&w.base, w.bytes));
+    {
+        const hipError_t em = hipMalloc((void**)&w.base, w.bytes);
+        if (em != hipSuccess) {                       // leave a clean "no workspace" state: the caller may retry with a smaller group
+            (void)hipGetLastError();
+            w = Workspace();
+            char b[200];
+            snprintf(b, sizeof b, "workspace of %.1f GB for %d images of %dx%d: %s", (double)off / 1e9, G, H, W, hipGetErrorString(em));
+            return fail(h, em == hipErrorOutOfMemory ? S2SR_E_CAPACITY : S2SR_E_HIP, b);
+        }
+    }
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
     HIPCHK(h, hipDeviceSynchronize());
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.D[2] = w.base + oD2; w.U0 = w.base + oU0;
@@ -585,8 +594,12 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
     const int per = mo.on() ? mo.kx * mo.ky : 1;
     const int NI = (B + per - 1) / per;                                       // images to push through the net
     const int IH = mo.on() ? mo.ky * (th + 1) - 1 : th, IW = mo.on() ? mo.kx * (tw + 1) - 1 : tw;
-    const int G = group_size(h, NI, IH, IW);
+    int G = group_size(h, NI, IH, IW);
     int rc = ensure_workspace(h, G, IH, IW, mo.on() ? th + 1 : 0, mo.on() ? tw + 1 : 0);
+    while (rc == S2SR_E_CAPACITY && G > 1) {          // the card is shared: fall back to smaller launch groups rather than fail the job
+        G = (G + 1) / 2;
+        rc = ensure_workspace(h, G, IH, IW, mo.on() ? th + 1 : 0, mo.on() ? tw + 1 : 0);
+    }
     if (rc) return rc;
     Workspace& w = h->ws;
     const size_t opx = (size_t)16 * th * tw;
