@@ -225,7 +225,7 @@ typedef struct s2sr_debug_config {
     int32_t fp8_hp_tail;    /* S2SR_FP8_TAIL=hp */
     int32_t graphs_on;      /* S2SR_GRAPH */
     int32_t trunk_wino;     /* 1: fp16 RDB conv1-4 in the row-Winograd F(2,3) form (S2SR_WINO) */
-    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC) */
+    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC); [1]: fp16 conv1-4 loader-wave form (S2SR_F16_LOADER) */
 } s2sr_debug_config;
 int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
 
@@ -240,7 +240,7 @@ int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
  * x is rounded to the operand format on the way in (fp16, or e4m3 at the handle's scales), so callers pass representable
  * values; `lo` ([N,64,H,W], kinds 1-2, may be NULL) is stored as e4m3(lo * 2^lo_exp); `skip` ([N,64,H,W]) as the
  * (fp16 hi, e4m3 lo) pair (kind 2) or fp16 (kind 5).  form: kind 0: 0 auto, 1 = 16x32 patches, 2 = 32x32 patches,
- * 3 = row-Winograd F(2,3); kind 3: the fp8_form bits. */
+ * 3 = row-Winograd F(2,3), 4 = 32x32 patches with the load-only fifth wave; kind 3: the fp8_form bits. */
 typedef struct s2sr_debug_trunk_args {
     int32_t kind, form;
     int32_t N, Cin, H, W;

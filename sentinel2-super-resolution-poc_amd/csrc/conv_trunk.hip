@@ -207,11 +207,16 @@ struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3
     static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : CT * 3 * NP;     // conv5: two fp16 blocks of x + one e4m3 plane of lo per 32 couts
 };
 
-template <int CT, int NP, int R, int EPI, bool TRACE>
-__global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
+// PROD = 1 (conv1-4 form only: its 208 registers fit two waves on a SIMD): a FIFTH wave issues every LDS-DMA instruction of the
+// workgroup and nothing else, as in conv_trunk_f8.  An LDS-DMA instruction holds its wave's issue port for ~60 cycles (12 per
+// stage and wave: a quarter of a stage with the matrix pipe starving behind an in-order wave); a wave that only loads can sit
+// in that stall for free.  One barrier per stage for everybody: the loader arrives when the NEXT stage has landed.
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0>
+__global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const ConvParams p) {
     using G = TG<CT, NP, R>;
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert(EPI == EPI_LRELU || kTrunk, "trunk kernel: conv1-4 (LRELU) and conv5 (RDB5 / RDB5_RRDB) only");
+    static_assert(PROD == 0 || (EPI == EPI_LRELU && !TRACE && S2SR_L2PF == 0), "loader wave: conv1-4 form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -313,6 +318,42 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         glds16<TRACE>(j < G::PI ? sb_i : wb_i, loff[sl], lds0 + slot_off + (uint32_t)j * 1024);
     };
 
+    // ---- the loader wave (PROD): the whole workgroup's DMA schedule
+    if (PROD && wave == 4) {
+        uint32_t loffP[G::PI];                                   // my 16 bytes of slab piece j
+#pragma unroll
+        for (int j = 0; j < G::PI; ++j) {
+            const int i = j * 64 + lane;
+            int q = i >> 1;
+            if (q >= G::SPX) q = 0;
+            const int ry = q / G::SW, rx = q - ry * G::SW;
+            const int h2 = (i & 1) ^ ((rx >> 3) & 1);
+            loffP[j] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
+        }
+        auto issue_stage = [&](uint32_t slot_off) __attribute__((always_inline)) {   // the stage under the cursor -> ring slot
+            cursor_next();
+#pragma unroll
+            for (int j = 0; j < G::PI; ++j) glds16<false>(sb_i, loffP[j], lds0 + slot_off + (uint32_t)j * 1024);
+#pragma unroll
+            for (int j = 0; j < G::WI; ++j) glds16<false>(wb_i, (uint32_t)(j * 1024 + lane * 16), lds0 + slot_off + (uint32_t)(G::PI + j) * 1024);
+        };
+        constexpr int NLAND = PROD ? G::NSTI * (R - 2) : 0;      // pieces that may still be in flight when the awaited stage has landed
+        static_assert(NLAND < 64, "vmcnt field is 6 bits");
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) issue_stage((uint32_t)(r * G::STAGE_BYTES));
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NLAND) : "memory");          // stage 0 has landed
+        const int total = my_tiles * NS;
+        uint32_t slot = 0;
+        for (int k = 0; k < total; ++k) {
+            // stage k + R - 1 goes where stage k - 1 was: the barrier of stage k - 1 (passed) released that slot
+            issue_stage(slot == 0 ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : slot - G::STAGE_BYTES);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NLAND) : "memory");      // stage k + 1 has landed: the barrier inside stage k
+            slot = (slot + G::STAGE_BYTES == (uint32_t)G::RING_BYTES) ? 0u : slot + G::STAGE_BYTES;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
     // ---- fragment addresses inside a slot: per-lane base + immediate
     uint32_t bbase[3];
 #pragma unroll
@@ -356,7 +397,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         for (int r = 0; r < R - 1; ++r) pf_next();                // the stages the DMA below fetches itself
     }
 #pragma unroll
-    for (int r = 0; r < R - 1; ++r) {
+    for (int r = 0; r < (PROD ? 0 : R - 1); ++r) {
         cursor_next();
 #pragma unroll
         for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, (uint32_t)(r * G::STAGE_BYTES));
@@ -372,7 +413,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         for (int r = R - 1; r < S2SR_L2PF; ++r) pf_next();        // (only when the prefetch runs further ahead than R-1 prologue rounds)
     }
     uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
-    wait_release_barrier<G::NW>();                                // stage 0 has landed (and the bias is visible)
+    if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the loader waited for the data
+    else wait_release_barrier<G::NW>();                           // stage 0 has landed (and the bias is visible)
     {
         const char* sb = smem;
 #pragma unroll
@@ -434,7 +476,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
         const char* sn = smem + next_off;
         // conv5 (kPull): the first stage of every patch but the first finds its DMA quota already issued by the epilogue before it
         const bool pulled = kPull && FIRST && !first_patch;
-        if (!pulled) cursor_next();                               // the stage R-1 ahead: its DMA rides on this stage
+        if (!pulled && !PROD) cursor_next();                      // the stage R-1 ahead: its DMA rides on this stage
         if (G::PFW > 0) pf_next();                                // and S2SR_L2PF stages beyond it: L2 prefetch
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
@@ -443,7 +485,8 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
                 // next stage landed + this slot released; everything below reads the NEXT slot
                 constexpr int NST = TrunkStores<EPI, CT, NP>::value;
                 constexpr int NEPI = (G::NW + NST < 63) ? G::NW + NST : 63;
-                if (FIRST && !first_patch) wait_release_barrier<NEPI>();
+                if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // my only vector-memory traffic are stores
+                else if (FIRST && !first_patch) wait_release_barrier<NEPI>();
                 else wait_release_barrier<G::NW>();
                 if (TRACE && p.trace && (p.dbg & 4) && lane == 0) {
                     if (kglob == 4) p.trace[(size_t)blockIdx.x * 24 + 0 * 8 + wave] = __builtin_amdgcn_s_memtime();
@@ -480,7 +523,7 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
-                if ((sl * (G::T - 3)) / G::PW == t && !pulled) dma_piece(sl, dma_off);
+                if ((sl * (G::T - 3)) / G::PW == t && !pulled && !PROD) dma_piece(sl, dma_off);
 #pragma unroll
             for (int k = 0; k < G::PFW; ++k)
                 if (((2 * k + 1) * (G::T - 3)) / (2 * G::PFW) == t) pf_piece(k);
@@ -765,12 +808,12 @@ __global__ void __launch_bounds__(256, 1) conv_trunk_f16(const ConvParams p) {
     }
 }
 
-template <int CT, int NP, int R, int EPI, bool TRACE>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0>
 hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     using G = TG<CT, NP, R>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::NW < 64, "vmcnt field is 6 bits");
-    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE>;
+    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD>;
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -803,7 +846,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     const int ntiles = q.tilesX * q.tilesY * p.N;
     int grid = ncu & ~7;
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PROD ? 320 : 256), G::LDS_BYTES, st, q);
     return hipGetLastError();
 }
 
@@ -1475,11 +1518,13 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
     if (ct == 1 && epi == EPI_LRELU) {
         if (force_form == 1) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);      // per-layer parity hook: name the patch form
         if (force_form == 2) return launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
+        if (force_form == 4) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);
         // 32x32 patches (8 rows per wave, 3-deep ring) unless that leaves most CUs without a patch (single tiles):
         // then 16x32 patches (4 rows per wave, 5-deep ring) spread the image over twice as many workgroups.  Both
         // forms accumulate in the same order, so the result does not depend on the choice.
         const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
         if (n32 < 192 && !trace) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
+        if (!trace && (p.f8_form & 16)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
         return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
     }
     if (ct == 2 && epi == EPI_RDB5) return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);

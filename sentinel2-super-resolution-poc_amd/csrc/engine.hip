@@ -138,6 +138,7 @@ struct s2sr_handle {
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
+    bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
@@ -351,6 +352,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
         return S2SR_OK;
     }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
+        if (h->f16_loader) p.f8_form |= 16;                      // (the f16 launcher reads only this bit of the field)
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
         if (e != hipErrorNotSupported) HIPCHK(h, e);
@@ -731,6 +733,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_MOSAIC")) h->mosaic_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_MOSAIC_KX")) h->mosaic_kx = atoi(g);
+    if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
@@ -1530,7 +1533,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0;
     return S2SR_OK;
 }
 
@@ -1791,6 +1794,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     }
     auto launch_one = [&](bool tr) -> hipError_t {
         if (wino) return launch_conv_trunk_wino(p, st);           // stamps whenever p.trace is set
+        if (h->f16_loader) p.f8_form |= 16;
         if (h->trunk_w4) {
             const hipError_t e = launch_conv_trunk(p, ct, epi, st, tr);
             if (e != hipErrorNotSupported) return e;

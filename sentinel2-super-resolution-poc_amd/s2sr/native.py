@@ -397,6 +397,7 @@ def _debug_config(self) -> dict:
     self._check(self._lib.s2sr_debug_get_config(self._h, C.byref(c)), "s2sr_debug_get_config")
     d = {n: int(getattr(c, n)) for n, _ in DebugConfig._fields_ if n != "reserved"}
     d["mosaic_on"] = int(c.reserved[0])
+    d["f16_loader"] = int(c.reserved[1])
     return d
 
 
