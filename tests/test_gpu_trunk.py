@@ -62,8 +62,8 @@ def _rand(rng, N, Cin, Cout, H, W):
 
 
 # form 1 = 16x32 patches / 5-deep ring (single tiles), form 2 = 32x32 patches / 3-deep ring (batches), form 3 = row-Winograd,
-# form 4 = form 2 with a fifth, load-only wave
-@pytest.mark.parametrize("form", [1, 2, 3, 4])
+# form 4 = form 2 with a fifth, load-only wave, form 5 = 8x32 patches / 7-deep ring (one tile on 256 CUs)
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("Cin,N,H,W", [(64, 1, 16, 32), (96, 2, 33, 45), (128, 1, 65, 31), (160, 1, 7, 100), (160, 2, 40, 64)])
 def test_f16_conv14_random(eng, form, Cin, N, H, W):
     rng = np.random.default_rng(Cin * 100 + H + form)
@@ -77,7 +77,7 @@ def test_f16_conv14_random(eng, form, Cin, N, H, W):
     assert np.all(err <= tol), (float(err.max()), float(np.abs(r).max()))
 
 
-@pytest.mark.parametrize("form", [1, 2, 3, 4])
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
 def test_f16_conv14_integer_layout(eng, form):
     """Exact data: every cout reads ONE input channel through ONE tap (the channel map is a permutation with a stride, the
     tap varies with the cout), so any swapped lane / tap / channel / row shows up as a wrong integer.  LeakyReLU runs in fp32
@@ -236,3 +236,4 @@ def test_f16_patch_forms_agree_bit_for_bit(eng):
         y1 = eng.debug_conv_trunk(K14, x, w, b, form=1)
         assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=2)), Cin
         assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=4)), Cin      # the loader-wave form: same stream of MFMAs
+        assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=5)), Cin      # 8x32 patches
