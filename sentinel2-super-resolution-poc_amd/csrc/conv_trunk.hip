@@ -1526,9 +1526,9 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         const long n32 = (long)((p.W + 31) / 32) * ((p.H + 31) / 32) * p.N;
         // ... and 8x32 patches (2 rows per wave, 7-deep ring) for a single tile: 256 patches for 256 CUs instead of 128 (one 256x256 tile
         // is launch-bound: 351 dependent launches; S2SR_SMALL8=0 keeps the 16x32 form)
-        if (n32 < 96 && !trace && !(p.f8_form & 32)) return launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
+        if (n32 < 96 && !trace && !(p.f16_form & 2)) return launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
         if (n32 < 192 && !trace) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
-        if (!trace && (p.f8_form & 16)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
+        if (!trace && (p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
         return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
     }
     if (ct == 2 && epi == EPI_RDB5) return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);

@@ -353,8 +353,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
         return S2SR_OK;
     }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
-        if (h->f16_loader) p.f8_form |= 16;                      // (the f16 launcher reads only bits 4-5 of the field)
-        if (!h->small8) p.f8_form |= 32;
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2);
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
         if (e != hipErrorNotSupported) HIPCHK(h, e);
@@ -1569,7 +1568,6 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
     hipStream_t st = h->stream;
     const int Hp = padded(H), Wp = padded(W);
     const size_t ppx = (size_t)Hp * Wp, blk = ppx * 32;
-    const size_t px = (size_t)H * W;
     auto pix = [&](int y, int x) { return (size_t)(y + 1) * Wp + (x + 1); };
     // ---- weights through the production device packers
     DevBuf d_w32, d_wp, d_b, d_ws;
@@ -1737,7 +1735,6 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
             });
         }
     }
-    (void)px;
     return S2SR_OK;
 }
 
@@ -1797,7 +1794,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     }
     auto launch_one = [&](bool tr) -> hipError_t {
         if (wino) return launch_conv_trunk_wino(p, st);           // stamps whenever p.trace is set
-        if (h->f16_loader) p.f8_form |= 16;
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2);
         if (h->trunk_w4) {
             const hipError_t e = launch_conv_trunk(p, ct, epi, st, tr);
             if (e != hipErrorNotSupported) return e;

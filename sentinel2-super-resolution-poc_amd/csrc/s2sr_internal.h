@@ -85,6 +85,8 @@ struct ConvParams {
     int32_t x_exp, g_exp;    // activation scales: x planes hold e4m3(x * 2^x_exp), growth planes e4m3(x_k * 2^g_exp)
     int32_t f8_form;         // conv_trunk_f8 conv1-4 kernel form (diagnostics): bit 0 no loader wave, bits 1-2 weight placement (0 default, 1 all
                              // streamed, 2 all resident), bit 3 two waves per SIMD -- from S2SR_FP8_LOADER / _WSTREAM / _W8 at s2sr_create
+    int32_t f16_form;        // conv_trunk_f16 conv1-4 kernel form: bit 0 = 32x32 patches with the load-only fifth wave (S2SR_F16_LOADER), bit 1 = single
+                             // tiles keep the 16x32-patch form instead of 8x32 (S2SR_SMALL8=0)
     int32_t lo_exp;          // conv_trunk_f16 conv5: the trunk's lo half is stored as e4m3(lo * 2^lo_exp) planes (xh_in, T, lo_skip)
     // Window mosaics (the AOI path, engine.hip forward_dev): equal-size windows of `_tile_process` (cnn_super_resolution.py:249-257) laid
     // out on a grid inside ONE image with a single zero row / column between neighbours -- the conv zero padding of both, at
