@@ -142,8 +142,8 @@ PRECISION_TEXT = {
            "operands (fp16 main term + e4m3 correction terms on the block-scaled fp8 MFMA): max-abs 8e-5..1.9e-4 vs the fp32 reference"),
     "fp8": ("the 345 RDB convs on e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, per-tensor-kind "
             "activation scales, fp32 accumulate, fp16 trunk); head/tail convs in plain fp16 (S2SR_FP8_TAIL=hp for the split forms): "
-            "measured max-abs 4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference, u8 within 1 LSB (93-95 % of bytes identical) -- NOT inside "
-            "the 1e-3 tolerance: an opt-in mode, not one to ship the reference's outputs with"),
+            "measured max-abs 4.1e-3 (rms 6e-4..8e-4) vs the fp32 reference on the noise goldens, 5.4e-3 (rms 1.0e-3, u8 within 2 LSB, 95 % of "
+            "bytes identical) on the reference's real image -- NOT inside the 1e-3 tolerance: an opt-in mode, not one to ship the reference's outputs with"),
     "fast": "fp16 MFMA operands everywhere, fp32 accumulate: max-abs 1.9e-3 vs the fp32 reference",
 }
 HBM_PEAK_GBS = 8000.0        # spec peak, MI355X_MICROARCH.md
@@ -396,7 +396,7 @@ def main():
             dt8, dtp8, st8, h0, h1, _ = timed(e8, a.steps, a.warmup, False)
             v8 = B * a.steps / dt8 * 16 * TILE * TILE / 1e6
             sec["fp8"] = {"value": round(v8, 2), "unit": "SR-MP/s", "ms_per_step": round(dt8 / a.steps * 1e3, 3), "dtype": "f8e4m3",
-                          "tolerance": "max-abs 4.1e-3 vs the fp32 reference (tests/test_gpu_net.py test_fp8_mode_*): OUTSIDE the 1e-3 "
+                          "tolerance": "max-abs 4.1e-3 (noise goldens) / 5.4e-3 (the reference's real image) vs the fp32 reference (tests/test_gpu_net.py test_fp8_mode_*, test_real_image_golden): OUTSIDE the 1e-3 "
                                        "target; BASELINE configs[4] arithmetic, opt-in (S2SR_PRECISION=fp8 / S2SR_FARM_PRECISION=fp8)",
                           "precision": PRECISION_TEXT["fp8"], "roofline": roofline_block(st8, "fp8", a.group, B, dtp8, a.steps, h0, h1)}
             e8.close()
