@@ -785,6 +785,37 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             issued += n;
             return n;
         };
+        if constexpr (EPI == EPI_LAST) {
+            // conv_last, folded form (p.nstage == 6): w_lo rides in the idle couts 8.. of the fp16 stages, so the
+            // x_hi planes never come in as e4m3 -- a patch is 4 fp16 stages + ONE pair (x_lo planes against w_hi).
+            // Six stages on a four-slot ring: stage j sits in slot j & 3, so patches alternate between
+            // "fp16 in slots 0..3, pair in (0,1)" and "fp16 in slots 2,3,0,1, pair in (2,3)".
+            if (NS == 6) {
+                while (k < S) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if (k < S) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                wait_pending(issued - 1 - k);
+                                const int n = plan_issue(k + 3);
+                                stage16_dx(smem + ((r + 2 * half) & 3) * G::STAGE_BYTES, n, sl0, sl1);
+                                ++k;
+                            }
+                            wait_pending(issued - 1 - (k + 1));
+                            const int n = plan_issue(k + 3);
+                            pair_body((uint32_t)((2 * half) * G::STAGE_BYTES), (uint32_t)((2 * half + 1) * G::STAGE_BYTES), n, sl0, sl1);
+                            k += 2;
+                            epilogue(it_c);
+                            init_acc();
+                            ++it_c;
+                            after_epi = true;
+                        }
+                    }
+                }
+                return;
+            }
+        }
         while (k < S) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -858,7 +889,8 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
     auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH>;
-    if (F8 && (p.nstage != 8 || p.seg_len != 4 || !p.src_lo)) return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes
+    if (F8 && ((p.nstage != 8 && !(EPI == EPI_LAST && p.nstage == 6 && p.fold_lo)) || p.seg_len != 4 || !p.src_lo))
+        return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes (conv_last folded: + 2)
     if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
     // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs, driven from
     // different threads (each handle has its own mutex, so this table needs one of its own)
@@ -1044,7 +1076,8 @@ uint8_t f32_to_e4m3(float f) {
 }
 
 // w: [cout][cin][taps] fp32 (taps = 9: OIHW 3x3; taps = 4: the 2x2 sub-pixel kernels below)
-static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* dst_host) {
+// fold (cout <= 8): fp16 stages carry [w_hi at couts 0.., w_lo at couts 8..] and only part 0 of the e4m3 planes follows
+static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* dst_host, bool fold = false) {
     const int CT = (cout + 31) / 32, ns = (cin + 15) / 16;
     f16* d16 = (f16*)dst_host;                                          // stages 0..ns-1: fp16 w_hi, [s][t][ct][lane][8]
     for (int s = 0; s < ns; ++s)
@@ -1053,11 +1086,17 @@ static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* ds
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
                         const int co = ct * 32 + (l & 31), ci = s * 16 + 8 * (l >> 5) + j;
-                        *d16++ = (co < cout && ci < cin) ? (f16)w[((size_t)co * cin + ci) * taps + t] : (f16)0.f;
+                        f16 o = (f16)0.f;
+                        if (co < cout && ci < cin) o = (f16)w[((size_t)co * cin + ci) * taps + t];
+                        else if (fold && ci < cin && co >= 8 && co - 8 < cout) {
+                            const float v = w[((size_t)(co - 8) * cin + ci) * taps + t];
+                            o = (f16)(v - (float)(f16)v);
+                        }
+                        *d16++ = o;
                     }
     uint8_t* d = (uint8_t*)d16;
     static const bool diag_no_wlo = [] { const char* e = getenv("S2SR_DIAG_NO_WLO"); return e && atoi(e) != 0; }();   // numerics diagnostic
-    for (int part = 0; part < 2; ++part)                                // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
+    for (int part = 0; part < (fold ? 1 : 2); ++part)                   // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
         for (int pl = 0; pl < 2; ++pl)
             for (int t = 0; t < taps; ++t)
                 for (int ct = 0; ct < CT; ++ct)
@@ -1075,7 +1114,7 @@ static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* ds
                             }
 }
 
-void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host) { pack_f8hp_taps(w, cin, cout, 9, dst_host); }
+void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host, bool fold) { pack_f8hp_taps(w, cin, cout, 9, dst_host, fold); }
 
 size_t conv_wpack_bytes_phase(int cin, int cout) { return (size_t)2 * ((cin + 15) / 16) * 4 * (2 * ((cout + 31) / 32)) * 1024; }
 

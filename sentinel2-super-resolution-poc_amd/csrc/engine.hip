@@ -138,6 +138,7 @@ struct s2sr_handle {
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
+    bool last_fold = true;        // S2SR_LAST_FOLD=0: conv_last (hp) reads all four e4m3 planes (8 stages) instead of folding w_lo into idle couts
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
@@ -736,6 +737,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_MOSAIC_KX")) h->mosaic_kx = atoi(g);
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_LAST_FOLD")) h->last_fold = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
@@ -842,10 +844,14 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
         // All the others (cin 64): x_hi*w_hi on the fp16 MFMA, x_lo*w_hi + x_hi*w_lo as e4m3 planes on the
         // block-scaled fp8 MFMA (twice the rate, half the bytes; 2^-15-relative error on 2^-11-sized terms).
         const bool f8 = split && idx != 0 && s.cin == 64;
-        const bool fold = split && !f8 && idx + 1 == nconv && s.cout <= 8;
+        // conv_last (3 couts of 32): w_lo rides in the idle couts 8..10 of the fp16 stages, so only the x_lo planes come in
+        // as e4m3 -- 6 stages instead of 8, 192 instead of 256 B per pixel read (S2SR_LAST_FOLD=0: the 8-stage form)
+        const bool last_fold = f8 && idx + 1 == nconv && s.cout <= 8 && h->last_fold;
+        const bool fold = (split && !f8 && idx + 1 == nconv && s.cout <= 8) || last_fold;
         const int nseg = !split ? 1 : ((idx == 0 || fold || f8) ? 2 : 3);
         cw.cin = s.cin; cw.cout = s.cout; cw.ct = (s.cout + 31) / 32;
         cw.seg_len = nb; cw.nstage = nseg * nb; cw.seg_lo_mask = (nseg == 3 || fold || f8) ? 0x2 : 0x0;
+        if (last_fold) cw.nstage = nb + 2;
         cw.f8 = f8;
         cw.fold = fold;
         cw.d_bias = h->pool_b + idx * 64;
@@ -872,9 +878,9 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
             HIPCHK(h, hipMemcpyAsync(hw.data(), d_blob + woff[idx], hw.size() * sizeof(float), hipMemcpyDeviceToHost, st));
             HIPCHK(h, hipStreamSynchronize(st));
             const float* pw = hw.data();
-            const size_t wb = conv_wpack_bytes_seg(s.cin, s.cout, nseg);
+            const size_t wb = last_fold ? (size_t)cw.nstage * 9 * cw.ct * 1024 : conv_wpack_bytes_seg(s.cin, s.cout, nseg);
             tmp.resize(wb);
-            if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data());
+            if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data(), last_fold);
             else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
             if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
                 const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
@@ -1535,7 +1541,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0;
     return S2SR_OK;
 }
 

@@ -144,7 +144,8 @@ size_t conv_wpack_bytes_seg(int cin, int cout, int nseg);
 // split-operand convs with fp8 correction terms (cin == 64): 4 fp16 stages [w_hi] + 4 e4m3 stages
 // [w_hi ch 0-31][w_hi ch 32-63][w_lo*2^11 ch 0-31][w_lo*2^11 ch 32-63]; an fp8 stage fragment is
 // [tap][ct][16-B half][cout row 0..31][16 channel bytes].  Same size as nseg = 2.
-void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host);
+// fold (cout <= 8, conv_last): 4 fp16 stages [w_hi at couts 0.. | w_lo at couts 8..] + the two e4m3 w_hi planes (6 stages)
+void pack_conv_weights_f8hp(const float* w, int cin, int cout, void* dst_host, bool fold = false);
 // sub-pixel form of the split-operand up-convs: four 2x2-tap kernels (one per output parity), same stage layout
 void pack_conv_weights_phase_f8hp(const float* w, int cin, int cout, int phase, void* dst_host);
 size_t conv_wpack_bytes_phase(int cin, int cout);

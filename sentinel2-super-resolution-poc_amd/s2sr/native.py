@@ -398,6 +398,7 @@ def _debug_config(self) -> dict:
     d = {n: int(getattr(c, n)) for n, _ in DebugConfig._fields_ if n != "reserved"}
     d["mosaic_on"] = int(c.reserved[0])
     d["f16_loader"] = int(c.reserved[1])
+    d["last_fold"] = int(c.reserved[2])
     return d
 
 

@@ -29,7 +29,7 @@ _ENG = {}
 
 
 _SWITCHES = ("S2SR_SMALL8", "S2SR_F16_LOADER", "S2SR_MOSAIC", "S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
-             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH")
+             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD")
 
 
 def engine(nb, precision=native.PREC_F16, **kw):
@@ -549,6 +549,31 @@ def test_window_mosaics_give_the_same_bytes(monkeypatch, prec):
     for _ in range(2):
         assert np.array_equal(on.forward_batch_u8(t256), r256) and np.array_equal(on.forward_batch_u8(t84), r84)
     on.close(); off.close()
+
+
+def test_conv_last_folded_and_eight_stage_forms(monkeypatch, golden_dir):
+    """conv_last in HP mode (conv3x3.hip, F8 schedule): the default 6-stage form carries w_lo as fp16 in the idle couts 8..10
+    and reads only the x_lo e4m3 planes; S2SR_LAST_FOLD=0 is the 8-stage form with x_hi as e4m3 against e4m3(w_lo * 2^11).
+    Both hold the HP bound on the goldens (1-, 2-, 6- and 23-block nets: odd and even patch counts per workgroup walk both
+    halves of the 6-on-4 ring), the u8 outputs of a ragged window differ by at most one count, and each handle reports its form."""
+    g3 = np.load(golden_dir / "g3_small_nets.npz")
+    g4 = np.load(golden_dir / "g4_full_nets.npz")
+    rng = np.random.default_rng(77)
+    xu = rng.integers(0, 256, (3, 75, 117, 3), dtype=np.uint8)
+    outs = {}
+    for fold in ("1", "0"):
+        for nb, g, key in ((1, g3, "y_b1"), (2, g3, "y_b2"), (6, g4, "y_b6"), (23, g4, "y_b23")):
+            e = _fresh(monkeypatch, nb, native.PREC_F16_HP, {"S2SR_LAST_FOLD": fold})
+            assert e.debug_config()["last_fold"] == int(fold)
+            err = float(np.abs(e.forward_f32(g["x"]) - g[key]).max())
+            if nb == 6:
+                outs[fold] = e.forward_batch_u8(xu)
+            e.close()
+            print(f"conv_last fold={fold}, {nb} blocks: max-abs err {err:.3e}")
+            assert err <= TOL_HP, (fold, nb, err)
+    d = np.abs(outs["1"].astype(np.int16) - outs["0"].astype(np.int16))
+    print(f"u8 outputs, folded vs 8-stage: {int((d != 0).sum())} of {d.size} differ, max {int(d.max())}")
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
 
 
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
