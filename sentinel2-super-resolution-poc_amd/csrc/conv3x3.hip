@@ -138,9 +138,9 @@ __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, __fmul_rn(v, 0
 // Epilogue stores are unconditional (lanes outside the image write to a trash line), so their
 // count per wave is a compile-time constant and the first wait after an epilogue can allow for
 // them exactly: the ring keeps its R-2 stages in flight across patch boundaries.
-template <int EPI, int CT, int NP, bool HPO>
+template <int EPI, int CT, int NP, int HPO>
 struct EpiStores {
-    static constexpr int value = (EPI == EPI_LRELU || EPI == EPI_BODY) ? CT * (HPO ? 4 : 2) * NP
+    static constexpr int value = (EPI == EPI_LRELU || EPI == EPI_BODY) ? CT * (HPO == 1 ? 4 : HPO == 2 ? 3 : 2) * NP
                                  : (EPI == EPI_RDB5)                   ? CT * 4 * NP
                                  : (EPI == EPI_RDB5_RRDB)              ? CT * 8 * NP
                                  : (EPI == EPI_FIRST)                  ? CT * 12 * NP
@@ -155,6 +155,19 @@ __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// F8 schedule: for how many stage waits after an epilogue its stores may stay in flight.  vmcnt retires in order, so the
+// wait for stage j may allow exactly the operations issued after stage j's DMA: the later stages' DMA and -- while the awaited
+// DMA is older than the epilogue -- the epilogue's NST stores.  Both stages in flight at the epilogue qualify (2); measured
+// against 1 (r03, conv_hr / conv_up): no difference, the stores are not what the next stages wait for.  1 ships.
+#ifndef S2SR_HPO_SHORT
+#define S2SR_HPO_SHORT 1   // short e4m3 encodings in the split-operand producers' epilogue (see there)
+#endif
+#ifndef S2SR_F8_STORE_SLACK
+#define S2SR_F8_STORE_SLACK 1
+#endif
+#ifndef S2SR_DIAG_F8
+#define S2SR_DIAG_F8 0   // timing diagnostics of the split-operand (F8) schedule: 1 no LDS-DMA, 2 no MFMA, 4 no epilogue, 8 epilogue without its stores
+#endif
 #define S2SR_STAMP(k)                                                              \
     do {                                                                           \
         if (TRACE && p.trace && !(p.dbg & 4) && tid == 0 && (k) < 20)              \
@@ -174,7 +187,8 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // bytes from the first plane, lanes 32-63 from the second) with a constant 2^-11 block scale: the
 // correction terms run at twice the fp16 rate on half the bytes.  An fp8 plane is 32 B per pixel,
 // byte-for-byte the geometry of an fp16 block-16 plane, so loader, ring and swizzle are shared.
-// HPO (their producers): besides the fp16 output, write those fp8 planes (p.T: lo8 p0, p1, hi8 p0, p1).
+// HPO (their producers): besides the fp16 output, write those fp8 planes (p.T: lo8 p0, p1, hi8 p0, p1); HPO = 2: only the lo8
+// planes (conv_hr when conv_last runs folded and never reads x_hi as e4m3).
 // PH >= 0 (F8 kernels only): sub-pixel form of "nearest-2x upsample, then 3x3 conv" (conv_up1 / conv_up2,
 // cnn_super_resolution.py:146-154).  The two upsampled rows 2y, 2y+1 are the same source row, so the
 // output pixels of row parity py = PH are a 2x2-tap conv of the SOURCE image with the 3x3 taps that
@@ -186,7 +200,7 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // (one parity per launch would write every other 32-B sector of each line: read-modify-write in L2/HBM).
 // The launch walks patches of the source image (p.H, p.W, sHp, sWp = source; Hp, Wp = the 2x output
 // tensor) and stores to (2y+py, 2x+q).
-template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false,
+template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, int HPO = 0, int OCC = 1, bool F8 = false,
           int PH = -1>
 __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
@@ -410,6 +424,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             }
     };
     auto dma_step = [&](int step, int n_issue) __attribute__((always_inline)) {   // `step` is a compile-time constant at every call
+#if S2SR_DIAG_F8 & 1
+        return;   // timing diagnostic (tools/tail_anatomy.sh): the F8 schedule without its LDS-DMA
+#endif
 #pragma unroll
         for (int sq = 0; sq < 2 * G::PW; ++sq) {
             constexpr int LASTSTEP = 3 * NBK - 1;
@@ -428,7 +445,10 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int np = 0; np < NP; ++np) asm volatile("" : "+v"(acc[ct][np]));
+            for (int np = 0; np < NP; ++np) {
+                if (WAVES == 4) asm volatile("" : "+a"(acc[ct][np]));   // one wave per SIMD: the accumulators live in AGPRs (see stage_body)
+                else asm volatile("" : "+v"(acc[ct][np]));
+            }
     };
     auto stage16_dx = [&](const char* buf, int n_issue, uint32_t sl_off, uint32_t sl_off1) __attribute__((always_inline)) {
         plan_dma(n_issue, sl_off, sl_off1);
@@ -466,7 +486,11 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                     for (int ct = 0; ct < CT; ++ct) {
                         const int bt = PH >= 0 ? dx - ct / CTR : dx;
                         if (bt < 0 || bt >= KT) continue;
+#if S2SR_DIAG_F8 & 2
+                        asm volatile("" ::"v"(a[dx & 1][dy][ct]), "v"(b[s & 1]));   // timing diagnostic: fragment reads kept, no MFMA
+#else
                         acc[ct][np] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[dx & 1][dy][ct], b[s & 1], acc[ct][np], 0, 0, 0);
+#endif
                     }
                 }
             }
@@ -523,7 +547,11 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                     for (int ct = 0; ct < CT; ++ct) {   // e4m3 x e4m3, scale_a = 2^0, scale_b = 2^-11 (E8M0 bytes 127, 116)
                         const int bt = PH >= 0 ? dx - ct / CTR : dx;
                         if (bt < 0 || bt >= KT) continue;
+#if S2SR_DIAG_F8 & 2
+                        asm volatile("" ::"v"(a8[dx & 1][dy][ct]), "v"(b8[s & 1]));
+#else
                         acc[ct][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[dx & 1][dy][ct], b8[s & 1], acc[ct][np], 0, 0, 0, 127, 0, 116);
+#endif
                     }
                 }
             }
@@ -609,6 +637,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 uint32_t lo8[4], hi8[4];   // e4m3 x4 per g (HPO): channels 8g+4hh .. +3 of fp8 plane ct
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    if (EPI == EPI_LAST && g > 0) continue;    // conv_last: couts 0..2 only (launch_t checks cout <= 3); 8.. are the folded w_lo sums
                     const int cb = ct * 32 + 8 * g + 4 * hh;   // first of this lane's 4 consecutive couts
                     f32x4 v;
 #pragma unroll
@@ -648,18 +677,57 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             live = live && t < p.mos_count;
                             oimg = (size_t)t; oy = y - wy * p.mos_py; ox = x - wx * p.mos_px; oH = p.mos_ry; oW = p.mos_rx;
                         }
+                        if (EPI == EPI_LAST) {
+                            // conv_last: couts 0..2 of the lanes hh == 0 (launch_t: cout <= 3, one cout tile; g > 0 skipped above).
+                            // One pixel index, one base address per output; no per-channel 64-bit index chains.
+                            float o3[3];
+                            uint32_t P = 0;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int co = cb + i;
-                            if (co >= p.cout || !live) continue;
-                            float o = v[i];
-                            if (EPI == EPI_LAST && g == 0 && p.fold_lo) o = __fadd_rn(o, acc[ct][np][4 + i]);   // + x*w_lo (couts 8..)
-                            if (EPI == EPI_DEBUG && p.act) o = lrelu(o);
-                            if (p.out_f32) p.out_f32[((oimg * p.cout + co) * oH + oy) * oW + ox] = o;
-                            if (EPI == EPI_LAST && p.out_u8) {
+                            for (int i = 0; i < 3; ++i) {
+                                o3[i] = p.fold_lo ? __fadd_rn(v[i], acc[ct][np][4 + i]) : v[i];   // + x*w_lo (couts 8..)
                                 // (out*255).clip(0,255).astype(uint8): truncation (cnn_super_resolution.py:232)
-                                const float q = fminf(fmaxf(__fmul_rn(o, 255.0f), 0.f), 255.f);
-                                p.out_u8[((oimg * oH + oy) * oW + ox) * 3 + co] = (uint8_t)(int)q;
+                                const float q = fminf(fmaxf(__fmul_rn(o3[i], 255.0f), 0.f), 255.f);
+                                P |= (uint32_t)(int)q << (8 * i);
+                            }
+                            const size_t plane = (size_t)oH * oW;
+                            const size_t pix = (oimg * (size_t)oH + (size_t)oy) * (size_t)oW + (size_t)ox;   // pixel index in [*, oH, oW]
+                            if (p.out_f32 && live && hh == 0) {   // fp32 copy (tests, enhance_f32): planar [img, cout, oH, oW]
+                                float* d = p.out_f32 + pix + oimg * (size_t)(p.cout - 1) * plane;
+#pragma unroll
+                                for (int i = 0; i < 3; ++i)
+                                    if (i < p.cout) d[(size_t)i * plane] = o3[i];
+                            }
+                            if (p.out_u8) {
+                                // u8 RGB rows: a wave's 32 pixels of one row are 96 contiguous bytes.  Each lane packs its pixel into
+                                // 24 bits, lanes 0..23 collect one dword each with two ds_bpermute and the segment goes out as whole
+                                // 32-B sectors (byte stores at stride 3 are partial-sector writes).  Taken when the 32 pixels are all
+                                // live, consecutive in one output row and start on a dword (wave-uniform test); else bytes.
+                                const uint32_t rowkey = (uint32_t)(oimg * (size_t)oH + (size_t)oy);
+                                const uint64_t lm = __builtin_amdgcn_ballot_w64(live);
+                                const int ox0 = __builtin_amdgcn_readlane(ox, 0);
+                                const bool uni = p.cout == 3 && (uint32_t)lm == 0xffffffffu &&
+                                                 __builtin_amdgcn_readlane((int)rowkey, 0) == __builtin_amdgcn_readlane((int)rowkey, 31) &&
+                                                 __builtin_amdgcn_readlane(ox, 31) == ox0 + 31 && (ox0 & 3) == 0 && (oW & 3) == 0;
+                                if (uni) {
+                                    const int p0 = (4 * lane) / 3, r8 = 8 * (4 * lane - 3 * p0);
+                                    const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0, (int)P);
+                                    const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * p0 + 4, (int)P);
+                                    const size_t pix0 = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)rowkey, 0) * (size_t)oW + (size_t)ox0;
+                                    if (lane < 24) *(uint32_t*)(p.out_u8 + pix0 * 3 + 4 * lane) = (a0 >> r8) | (a1 << (24 - r8));
+                                } else if (live && hh == 0) {
+                                    uint8_t* d = p.out_u8 + pix * 3;
+#pragma unroll
+                                    for (int i = 0; i < 3; ++i)
+                                        if (i < p.cout) d[i] = (uint8_t)(P >> (8 * i));
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int co = cb + i;
+                                if (co >= p.cout || !live) continue;
+                                const float o = p.act ? lrelu(v[i]) : v[i];
+                                if (p.out_f32) p.out_f32[((oimg * p.cout + co) * oH + oy) * oW + ox] = o;
                             }
                         }
                     } else {
@@ -674,19 +742,43 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             lpk[g] = __builtin_bit_cast(u32x2, lv);
                         } else if (HPO) {
                             // e4m3 copies for the consumer's correction terms: lo*2^11 and hi, clamped to the
-                            // finite range (v_cvt_pk_fp8_f32 turns anything past 448 into NaN)
-                            float l4[4], h4[4];
+                            // finite range (the fp8 conversions turn anything past 448 into NaN)
+                            // lo, short form (S2SR_HPO_SHORT; same bytes as the long one, tools/check_hpo_forms.py): v - fp16(v) in ONE
+                            // v_fma_mix_f32 that reads the packed half in place, the clamp on the unscaled value, the 2^11 inside
+                            // v_cvt_scalef32_pk_fp8_f32 (it divides by the power of two of its scale operand): 2.5 instead of 5.5
+                            // instructions per value.  (hi straight from the packed pair -- v_pk_min/max_f16 +
+                            // v_cvt_scalef32_pk_fp8_f16 -- was tried too and does NOT give the long form's bytes; it stays long.)
+                            typedef short v2s __attribute__((ext_vector_type(2)));
+                            if (S2SR_HPO_SHORT) {
+                                float q[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                l4[i] = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[i], (float)hv[i]), 2048.0f), -448.0f, 448.0f);
-                                h4[i] = __builtin_amdgcn_fmed3f((float)hv[i], -448.0f, 448.0f);
+                                for (int i = 0; i < 4; ++i) {
+                                    float d;
+                                    if (i & 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk[g][i >> 1]), "v"(v[i]));
+                                    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpk[g][i >> 1]), "v"(v[i]));
+                                    q[i] = __builtin_amdgcn_fmed3f(d, -448.0f / 2048.0f, 448.0f / 2048.0f);
+                                }
+                                v2s w8 = {0, 0};
+                                w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[0], q[1], 1.0f / 2048.0f, false);
+                                w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[2], q[3], 1.0f / 2048.0f, true);
+                                lo8[g] = __builtin_bit_cast(uint32_t, w8);
+                            } else {
+                                float l4[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    l4[i] = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[i], (float)hv[i]), 2048.0f), -448.0f, 448.0f);
+                                int lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
+                                lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], lw, true);
+                                lo8[g] = (uint32_t)lw;
                             }
-                            int lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
-                            lw = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], lw, true);
-                            int hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[0], h4[1], 0, false);
-                            hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[2], h4[3], hw, true);
-                            lo8[g] = (uint32_t)lw;
-                            hi8[g] = (uint32_t)hw;
+                            if (HPO == 1) {
+                                float h4[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) h4[i] = __builtin_amdgcn_fmed3f((float)hv[i], -448.0f, 448.0f);
+                                int hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[0], h4[1], 0, false);
+                                hw = __builtin_amdgcn_cvt_pk_fp8_f32(h4[2], h4[3], hw, true);
+                                hi8[g] = (uint32_t)hw;
+                            }
                         }
                     }
                 }
@@ -701,7 +793,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         const auto r1 = __builtin_amdgcn_permlane32_swap(lo[1], hi[1], false, false);
                         u32x4 o;
                         o[0] = r0[0]; o[1] = r1[0]; o[2] = r0[1]; o[3] = r1[1];
-                        *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(rc * 2 + bk) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
+                        if ((S2SR_DIAG_F8 & 8) && F8) asm volatile("" ::"v"(o));   // timing diagnostic: the epilogue's arithmetic without its stores
+                        else *(u32x4*)(ok[np] ? p.dst + (size_t)n * p.dst_img + (size_t)(rc * 2 + bk) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
                         if (kTrunk || EPI == EPI_FIRST) {
                             u32x2 llo = lpk[2 * bk], lhi = lpk[2 * bk + 1];
                             const auto q0 = __builtin_amdgcn_permlane32_swap(llo[0], lhi[0], false, false);
@@ -715,13 +808,14 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         // the lane holds dwords 2g+hh of the pixel's 32 plane bytes; after the swaps
                         // lanes 0-31 hold dwords 0-3, lanes 32-63 dwords 4-7: one 16-B store each
 #pragma unroll
-                        for (int w = 0; w < 2; ++w) {
+                        for (int w = 0; w < (HPO == 1 ? 2 : 1); ++w) {
                             const uint32_t* d = w ? hi8 : lo8;
                             const auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
                             const auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
                             u32x4 o;
                             o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
-                            *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(2 * w + rc) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
+                            if ((S2SR_DIAG_F8 & 8) && F8) asm volatile("" ::"v"(o));
+                            else *(u32x4*)(ok[np] ? (char*)p.T + ln + (size_t)(2 * w + rc) * oblk + opix[np] * 32 + qoff + hh * 16 : trash) = o;
                         }
                     }
                 }
@@ -752,6 +846,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 
     int k = 0, it_c = 0, st_c = 0;
     bool after_epi = false;
+    int epi_age = 8;   // F8 schedule: waits since the last epilogue (saturating)
     constexpr int NST = EpiStores<EPI, CT, NP, HPO>::value;
     constexpr int NW = G::PW * (R - 2);
     if constexpr (F8) {
@@ -762,7 +857,8 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
         constexpr int PWn = G::PW;
         int issued = S < R - 1 ? S : R - 1;
         auto wait_pending = [&](int pend) __attribute__((always_inline)) {
-            const bool epi = after_epi && NST > 0;
+            const int age = epi_age < 8 ? epi_age++ : 8;
+            const bool epi = NST > 0 && age < S2SR_F8_STORE_SLACK;
             if (pend >= 2) {
                 if (epi) wait_vm_barrier<(NST > 0 ? 2 * PWn + NST : 2 * PWn)>();
                 else wait_vm_barrier<2 * PWn>();
@@ -806,10 +902,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             const int n = plan_issue(k + 3);
                             pair_body((uint32_t)((2 * half) * G::STAGE_BYTES), (uint32_t)((2 * half + 1) * G::STAGE_BYTES), n, sl0, sl1);
                             k += 2;
+#if !(S2SR_DIAG_F8 & 4)
                             epilogue(it_c);
+#endif
                             init_acc();
                             ++it_c;
                             after_epi = true;
+                            epi_age = 0;
                         }
                     }
                 }
@@ -831,10 +930,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                 pair_body((uint32_t)((2 * pr) * G::STAGE_BYTES), (uint32_t)((2 * pr + 1) * G::STAGE_BYTES), n, sl0, sl1);
                 k += 2;
             }
+#if !(S2SR_DIAG_F8 & 4)
             epilogue(it_c);
+#endif
             init_acc();
             ++it_c;
             after_epi = true;
+            epi_age = 0;
         }
         return;
     }
@@ -882,7 +984,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 // ------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------
-template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, bool HPO = false, int OCC = 1, bool F8 = false,
+template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, int HPO = 0, int OCC = 1, bool F8 = false,
           int PH = -1>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
@@ -892,6 +994,7 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     if (F8 && ((p.nstage != 8 && !(EPI == EPI_LAST && p.nstage == 6 && p.fold_lo)) || p.seg_len != 4 || !p.src_lo))
         return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes (conv_last folded: + 2)
     if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
+    if (EPI == EPI_LAST && (p.cout > 3 || CT != 1)) return hipErrorInvalidValue;   // its epilogue writes couts 0..2 (RGB) only
     // the dynamic-LDS opt-in is per device: a process may hold handles on several GPUs, driven from
     // different threads (each handle has its own mutex, so this table needs one of its own)
     static std::mutex attr_mu;
@@ -923,6 +1026,12 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     const int ntiles = q.tilesX * q.tilesY * p.N;
     int grid = (ncu * OCC) & ~7;              // OCC persistent workgroups per CU
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
+#if S2SR_DIAG_F8
+    if (F8) {   // diagnostic builds only: run the split-operand convs on a subset of the CUs (S2SR_DIAG_GRID workgroups, multiple of 8)
+        static const int dg = [] { const char* e = getenv("S2SR_DIAG_GRID"); return e ? atoi(e) & ~7 : 0; }();
+        if (dg > 0 && dg < grid) grid = dg;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), G::LDS_BYTES, st, q);
     return hipGetLastError();
 }
@@ -960,11 +1069,17 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
 
 hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_out, hipStream_t st, bool f8_in) {
     if (f8_in) {   // split-operand mode: fp16 main term + fp8 correction planes in; lo_out: fp8 planes out as well
-        if (ct == 2 && lo_out) {
-            if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, true, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, true, 1, true>(p, st);
-            if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, true, 1, true>(p, st);
+        if (p.tail_form & 1) {   // one wave per SIMD: 4 waves x 4 rows, the same 16x32 patch and ring
+            if (ct == 2 && lo_out && epi == EPI_LRELU && !up) return launch_t<2, EPI_LRELU, false, 4, 4, 4, false, 1, 1, true>(p, st);
+            if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 4, 4, 4, false, 0, 1, true>(p, st);
         }
-        if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 8, 2, 4, false, false, 1, true>(p, st);
+        if (ct == 2 && lo_out && epi == EPI_LRELU && !up && (p.tail_form & 2))   // conv_hr in front of a folded conv_last: no hi8 planes out
+            return launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true>(p, st);
+        if (ct == 2 && lo_out) {
+            if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, 1, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 1, 1, true>(p, st);
+            if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true>(p, st);
+        }
+        if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 8, 2, 4, false, 0, 1, true>(p, st);
         return hipErrorInvalidValue;
     }
     if (lo_out) return hipErrorInvalidValue;
@@ -986,12 +1101,16 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
 // one ROW parity of a split-operand up-conv in sub-pixel form (both column parities inside the launch;
 // p.H, p.W = source dims, p.Hp, p.Wp = 2x tensor)
 hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f8) {
+    if (f8 && (p.tail_form & 1)) {   // one wave per SIMD: 4 waves x 2 source rows
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 1>(p, st);
+    }
     if (f8) {
-        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 0>(p, st);
-        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, true, 1, true, 1>(p, st);
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 1>(p, st);
     } else {   // plain fp16 mode: the same four fp16 stages, no correction planes in or out
-        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, false, 1, false, 0>(p, st);
-        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, false, 1, false, 1>(p, st);
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, 0, 1, false, 0>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 2, 4, false, 0, 1, false, 1>(p, st);
     }
     return hipErrorInvalidValue;
 }

@@ -138,6 +138,7 @@ struct s2sr_handle {
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
     int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
+    bool tail_w4 = false;         // S2SR_TAIL_W4=1: split-operand tail convs (up1, up2, hr, last) as 4 waves x twice the rows (one wave per SIMD)
     bool last_fold = true;        // S2SR_LAST_FOLD=0: conv_last (hp) reads all four e4m3 planes (8 stages) instead of folding w_lo into idle couts
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
@@ -337,6 +338,9 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     p.seg_len = cw.seg_len;
     p.seg_lo_mask = cw.seg_lo_mask;
     p.fold_lo = cw.fold ? 1 : 0;
+    p.tail_form = h->tail_w4 ? 1 : 0;
+    // conv_hr: a folded conv_last (the last conv) reads x_lo planes only, so the e4m3(x_hi) planes need not be written
+    if (fam == F_HR && lo_out && !h->convs.empty() && h->convs.back().f8 && h->convs.back().fold) p.tail_form |= 2;
     p.trash = h->d_trash;
     const double px = (double)p.N * p.H * p.W;
     const double flops = 2.0 * 9.0 * cw.cin * cw.cout * px;
@@ -370,6 +374,7 @@ int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams 
                     int oHp, int oWp) {
     p.N = n; p.H = Hs; p.W = Ws; p.sHp = sHp; p.sWp = sWp; p.Hp = oHp; p.Wp = oWp;
     p.bias = cw.d_bias; p.nstage = cw.f8 ? 8 : 4; p.seg_len = 4; p.seg_lo_mask = cw.f8 ? 0x2 : 0x0; p.fold_lo = 0;
+    p.tail_form = h->tail_w4 ? 1 : 0;
     p.trash = h->d_trash;
     const double px = (double)n * Hs * Ws;
     for (int k = 0; k < 2; ++k) {
@@ -738,6 +743,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_LAST_FOLD")) h->last_fold = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_TAIL_W4")) h->tail_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
@@ -1541,7 +1547,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0;
     return S2SR_OK;
 }
 

@@ -399,6 +399,7 @@ def _debug_config(self) -> dict:
     d["mosaic_on"] = int(c.reserved[0])
     d["f16_loader"] = int(c.reserved[1])
     d["last_fold"] = int(c.reserved[2])
+    d["tail_w4"] = int(c.reserved[3])
     return d
 
 

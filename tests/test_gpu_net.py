@@ -29,7 +29,7 @@ _ENG = {}
 
 
 _SWITCHES = ("S2SR_SMALL8", "S2SR_F16_LOADER", "S2SR_MOSAIC", "S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
-             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD")
+             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD", "S2SR_TAIL_W4")
 
 
 def engine(nb, precision=native.PREC_F16, **kw):
@@ -574,6 +574,24 @@ def test_conv_last_folded_and_eight_stage_forms(monkeypatch, golden_dir):
     d = np.abs(outs["1"].astype(np.int16) - outs["0"].astype(np.int16))
     print(f"u8 outputs, folded vs 8-stage: {int((d != 0).sum())} of {d.size} differ, max {int(d.max())}")
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+def test_tail_convs_one_wave_per_simd_form_gives_the_same_bytes(monkeypatch, golden_dir):
+    """S2SR_TAIL_W4 picks the 4-wave instantiations of the split-operand tail convs (conv_up1 / conv_up2 sub-pixel forms, conv_hr,
+    conv_last; conv3x3.hip F8 schedule with WAVES = 4 and twice the rows per wave).  Same patch, same ring, same accumulation
+    order per pixel: the float outputs are bit-identical to the 8-wave forms on ragged windows and on the goldens."""
+    g4 = np.load(golden_dir / "g4_full_nets.npz")
+    rng = np.random.default_rng(78)
+    xs = [rng.random((2, 3, 37, 53), dtype=np.float32), rng.random((1, 3, 64, 96), dtype=np.float32), g4["x"]]
+    outs = {}
+    for w4 in ("0", "1"):
+        e = _fresh(monkeypatch, 6, native.PREC_F16_HP, {"S2SR_TAIL_W4": w4})
+        assert e.debug_config()["tail_w4"] == int(w4)
+        outs[w4] = [e.forward_f32(x) for x in xs]
+        e.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+    assert float(np.abs(outs["1"][2] - g4["y_b6"]).max()) <= TOL_HP
 
 
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
