@@ -124,6 +124,9 @@ struct s2sr_handle {
     s2sr_kstat stats[F_COUNT];
     hipStream_t copy_stream = nullptr;          // device-to-host copies behind the compute stream
     std::vector<hipEvent_t> group_done;
+    void* stage_buf[2] = {nullptr, nullptr};    // pinned staging slices of the device-to-host path (d2h_staged)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool d2h_staged_on = true;                  // S2SR_D2H_STAGED=0: hipMemcpyAsync straight into the caller's (pageable) buffer
     // hipGraph replay of repeated groups
     float* d_calib = nullptr;     // fp8 calibration: [0] max |x| of the trunk, [1] max |x_k| of the growth planes (device)
     bool fp8_hp_tail = false;     // S2SR_PREC_FP8: the six head / tail convs in plain fp16 (their ~2e-3 is below the trunk's e4m3
@@ -744,6 +747,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_LAST_FOLD")) h->last_fold = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TAIL_W4")) h->tail_w4 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_D2H_STAGED")) h->d2h_staged_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
@@ -783,6 +787,10 @@ void s2sr_destroy(s2sr_handle* h) {
     for (EvRec& r : h->evs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : h->group_done) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (h->stage_buf[i]) hipHostFree(h->stage_buf[i]);
+        if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+    }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -973,6 +981,38 @@ int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, in
     return forward_dev(h, st, (const uint8_t*)d_tiles, nullptr, B, th, tw, (uint8_t*)d_out, nullptr);
 }
 
+// Device -> caller's host buffer, `bytes` from `src`, ordered behind everything already on the copy stream; returns when the
+// bytes are in `dst`.  The caller's buffer is ordinary pageable memory (a numpy array): handed to hipMemcpyAsync directly, the
+// runtime moves it with copy KERNELS through its own staging at ~6 GB/s, and those kernels take CUs from the persistent conv
+// workgroups of the chunk computing meanwhile (4096 x 4096 AOI: +20 ms of compute under 130 ms of copies).  Here: two pinned
+// 32-MB slices filled by the DMA engines (pinned destination), emptied by this thread's memcpy while the next slice flies.
+static constexpr size_t kStageBytes = 32u << 20;
+static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t bytes) {
+    if (!h->d2h_staged_on || bytes < (64u << 20)) {   // short copies: the runtime's own path is as fast (measured: 50 MB, 58 vs 60 ms per 1024 x 1024 call)
+        HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        return S2SR_OK;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!h->stage_buf[i]) HIPCHK(h, hipHostMalloc(&h->stage_buf[i], kStageBytes, hipHostMallocDefault));
+        if (!h->stage_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+    }
+    const size_t nsl = (bytes + kStageBytes - 1) / kStageBytes;
+    auto len = [&](size_t k) { return k + 1 < nsl ? kStageBytes : bytes - k * kStageBytes; };
+    for (size_t k = 0; k < nsl + 2; ++k) {
+        const int i = (int)(k & 1);
+        if (k >= 2) {   // slice k-2 sits in buffer i
+            HIPCHK(h, hipEventSynchronize(h->stage_ev[i]));
+            memcpy(dst + (k - 2) * kStageBytes, h->stage_buf[i], len(k - 2));
+        }
+        if (k < nsl) {
+            HIPCHK(h, hipMemcpyAsync(h->stage_buf[i], src + k * kStageBytes, len(k), hipMemcpyDeviceToHost, h->copy_stream));
+            HIPCHK(h, hipEventRecord(h->stage_ev[i], h->copy_stream));
+        }
+    }
+    return S2SR_OK;
+}
+
 int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, uint8_t* out) {
     if (!h || !tiles || !out) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1003,8 +1043,7 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     for (int g = 0; g < ngroups; ++g) {
         const int g0 = g * G, n = (B - g0 < G) ? (B - g0) : G;
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[g], 0));
-        HIPCHK(h, hipMemcpyAsync(out + g0 * tout, (const uint8_t*)h->d_scratch[1] + g0 * tout, n * tout, hipMemcpyDeviceToHost,
-                                 h->copy_stream));
+        if ((rc = d2h_staged(h, out + g0 * tout, (const uint8_t*)h->d_scratch[1] + g0 * tout, n * tout))) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1131,9 +1170,15 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         // copy runs on the copy stream under the next chunk's compute.  A chunk holds whole launch groups: for windows that
         // travel as mosaics (forward_dev) rows in multiples of what fills a mosaic, and as many mosaics as the workspace
         // allows -- the patch count of a launch must be large against the 256 workgroups (one 4 x 4 mosaic of 276-pixel
-        // windows is 1225 patches = 4.8 per CU, five rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24) -- but at
-        // least three chunks where the image has that many, so that the copies overlap.
-        int rpc = ny, nchunks = 1;
+        // windows is 1225 patches = 4.8 per CU, five rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24).
+        // Chunk sizes.  The device-to-host copy of a chunk's band hides under the NEXT chunk's compute and only the last band's
+        // copy is exposed, so chunks shrink towards the end (a row of 276-pixel windows computes ~6x longer than its 13 MB band
+        // takes to reach pageable host memory; a chunk may be up to 4x its successor).  What a small chunk costs is the rounding
+        // of its patch count to whole rounds of the persistent workgroups in the trunk convs (32 x 32 patches; a 4 x 4 mosaic
+        // of 276-pixel windows = 1225 patches = 4.8 rounds of 256: 1, 2, 3, 4 mosaics lose 4.3 %, 5 or 10 lose 0.3 %).  The
+        // tail (last, middle) is searched over small sizes for the fewest rounds + exposed copy; the rest goes in front in
+        // workspace-sized pieces.  4096 x 4096 at 256/10: 16 rows of 16 windows -> 10 + 5 + 1.
+        std::vector<int> chunk_r0;   // first window row of each chunk, plus ny at the end
         {
             const Mosaic mo = pick_mosaic(h, T, wh, ww);
             const int per = mo.on() ? mo.kx * mo.ky : 1;
@@ -1143,12 +1188,36 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             const int units = (ny + r_min - 1) / r_min;                                 // ... and how many such row units the image has
             int u_max = gw / nx / r_min;                                                // units per chunk the workspace allows
             if (u_max < 1) u_max = 1;
-            nchunks = (units + u_max - 1) / u_max;
-            const int want = units < 3 ? units : 3;
-            if (nchunks < want) nchunks = want;
-            rpc = r_min * ((units + nchunks - 1) / nchunks);                            // evenly filled (16 rows: 6 + 5 + 5, not 6 + 6 + 4)
-            nchunks = (ny + rpc - 1) / rpc;
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+            const long pimg = mo.on() ? (long)((mo.ky * (wh + 1) - 1 + 31) / 32) * ((mo.kx * (ww + 1) - 1 + 31) / 32)
+                                      : (long)((wh + 31) / 32) * ((ww + 31) / 32);      // 32 x 32 patches per launch image
+            auto rounds = [&](int u) -> double {                                        // trunk-conv rounds of a chunk of u units
+                const long imgs = ((long)u * r_min * nx + per - 1) / per;
+                return (double)((imgs * pimg + ncu - 1) / ncu);
+            };
+            const double copy_per_unit = (double)r_min * nx * pimg / per / ncu / 6.0;  // exposed copy of one unit, in rounds
+            int best_last = 1, best_mid = 0;
+            double best = 1e300;
+            for (int last = 1; last <= 3 && last <= units; ++last)
+                for (int mid = 0; mid <= 12 && last + mid <= units; ++mid) {
+                    if (mid > u_max || last > u_max || mid > 4 * last) continue;
+                    const int front = units - last - mid;
+                    if (front > 0 && mid == 0 && front > 4 * last) continue;            // a big chunk straight in front of the last one
+                    if (front > 0 && mid > 0 && front > 6 * mid && front <= u_max) continue;
+                    double c = rounds(last) + (mid ? rounds(mid) : 0.0) + last * copy_per_unit;
+                    for (int left = front; left > 0;) { const int u = left < u_max ? left : u_max; c += rounds(u); left -= u; }
+                    if (c < best - 1e-9) { best = c; best_last = last; best_mid = mid; }
+                }
+            std::vector<int> sizes;                                                     // in units, front to back
+            for (int left = units - best_last - best_mid; left > 0;) { const int u = left < u_max ? left : u_max; sizes.push_back(u); left -= u; }
+            if (best_mid) sizes.push_back(best_mid);
+            sizes.push_back(best_last);
+            int r = 0;
+            for (int u : sizes) { chunk_r0.push_back(r); r += u * r_min; }
+            chunk_r0.push_back(ny);
         }
+        const int nchunks = (int)chunk_r0.size() - 1;
         if (!out_f32 && nchunks > 1) {
             const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
             while ((int)h->group_done.size() < nchunks) {
@@ -1159,7 +1228,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             uint8_t* d_img_out = (uint8_t*)h->d_scratch[1];
             int yb = 0, prev_yb = 0, prev_ye = 0;
             for (int c = 0; c < nchunks; ++c) {
-                const int r0 = c * rpc, r1 = (r0 + rpc < ny) ? r0 + rpc : ny;
+                const int r0 = chunk_r0[c], r1 = chunk_r0[c + 1] < ny ? chunk_r0[c + 1] : ny;
                 const int t0 = r0 * nx, n = (r1 - r0) * nx;
                 rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[2] + t0 * win_in, nullptr, n, wh, ww,
                                  (uint8_t*)h->d_scratch[4] + t0 * win_out, nullptr);
@@ -1173,15 +1242,15 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
                 HIPCHK(h, hipEventRecord(h->group_done[c], st));
                 if (c > 0 && prev_ye > prev_yb) {
                     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[c - 1], 0));
-                    HIPCHK(h, hipMemcpyAsync(out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                             (size_t)(prev_ye - prev_yb) * OW * 3, hipMemcpyDeviceToHost, h->copy_stream));
+                    if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
+                                         (size_t)(prev_ye - prev_yb) * OW * 3))) return rc;
                 }
                 prev_yb = yb; prev_ye = ye; yb = ye;
             }
             if (prev_ye > prev_yb) {
                 HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks - 1], 0));
-                HIPCHK(h, hipMemcpyAsync(out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                         (size_t)(prev_ye - prev_yb) * OW * 3, hipMemcpyDeviceToHost, h->copy_stream));
+                if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
+                                     (size_t)(prev_ye - prev_yb) * OW * 3))) return rc;
             }
             HIPCHK(h, hipStreamSynchronize(h->copy_stream));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -1193,8 +1262,14 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         if (out_f32) HIPCHK(h, launch_stitch_f32((const float*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (float*)h->d_scratch[1], st));
         else HIPCHK(h, launch_stitch_u8((const uint8_t*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (uint8_t*)h->d_scratch[1], st));
     }
-    if (out_f32) HIPCHK(h, hipMemcpyAsync(out_f32, h->d_scratch[1], opx * 4, hipMemcpyDeviceToHost, st));
-    else HIPCHK(h, hipMemcpyAsync(out_u8, h->d_scratch[1], opx, hipMemcpyDeviceToHost, st));
+    if (h->group_done.empty()) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->group_done.push_back(e);
+    }
+    HIPCHK(h, hipEventRecord(h->group_done[0], st));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[0], 0));
+    if ((rc = d2h_staged(h, out_f32 ? (uint8_t*)out_f32 : out_u8, (const uint8_t*)h->d_scratch[1], opx * (out_f32 ? 4 : 1)))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     return S2SR_OK;
 }
