@@ -987,8 +987,10 @@ int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, in
 // workgroups of the chunk computing meanwhile (4096 x 4096 AOI: +20 ms of compute under 130 ms of copies).  Here: two pinned
 // 32-MB slices filled by the DMA engines (pinned destination), emptied by this thread's memcpy while the next slice flies.
 static constexpr size_t kStageBytes = 32u << 20;
-static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t bytes) {
-    if (!h->d2h_staged_on || bytes < (64u << 20)) {   // short copies: the runtime's own path is as fast (measured: 50 MB, 58 vs 60 ms per 1024 x 1024 call)
+// `exposed`: nothing computes under this copy (the last band, or the only one): below 128 MB the runtime's own path is then as
+// fast or faster (50 MB: 58.1 vs 60.3 ms per 1024 x 1024 call), and there are no conv workgroups for its copy kernels to displace.
+static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t bytes, bool exposed) {
+    if (!h->d2h_staged_on || bytes < (exposed ? (128u << 20) : (24u << 20))) {
         HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(h, hipStreamSynchronize(h->copy_stream));
         return S2SR_OK;
@@ -1043,7 +1045,7 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     for (int g = 0; g < ngroups; ++g) {
         const int g0 = g * G, n = (B - g0 < G) ? (B - g0) : G;
         HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[g], 0));
-        if ((rc = d2h_staged(h, out + g0 * tout, (const uint8_t*)h->d_scratch[1] + g0 * tout, n * tout))) return rc;
+        if ((rc = d2h_staged(h, out + g0 * tout, (const uint8_t*)h->d_scratch[1] + g0 * tout, n * tout, g + 1 == ngroups))) return rc;
     }
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1243,14 +1245,14 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
                 if (c > 0 && prev_ye > prev_yb) {
                     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[c - 1], 0));
                     if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                         (size_t)(prev_ye - prev_yb) * OW * 3))) return rc;
+                                         (size_t)(prev_ye - prev_yb) * OW * 3, false))) return rc;
                 }
                 prev_yb = yb; prev_ye = ye; yb = ye;
             }
             if (prev_ye > prev_yb) {
                 HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks - 1], 0));
                 if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                     (size_t)(prev_ye - prev_yb) * OW * 3))) return rc;
+                                     (size_t)(prev_ye - prev_yb) * OW * 3, true))) return rc;
             }
             HIPCHK(h, hipStreamSynchronize(h->copy_stream));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -1269,7 +1271,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
     }
     HIPCHK(h, hipEventRecord(h->group_done[0], st));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[0], 0));
-    if ((rc = d2h_staged(h, out_f32 ? (uint8_t*)out_f32 : out_u8, (const uint8_t*)h->d_scratch[1], opx * (out_f32 ? 4 : 1)))) return rc;
+    if ((rc = d2h_staged(h, out_f32 ? (uint8_t*)out_f32 : out_u8, (const uint8_t*)h->d_scratch[1], opx * (out_f32 ? 4 : 1), true))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     return S2SR_OK;
 }

@@ -29,7 +29,7 @@ _ENG = {}
 
 
 _SWITCHES = ("S2SR_SMALL8", "S2SR_F16_LOADER", "S2SR_MOSAIC", "S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
-             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD", "S2SR_TAIL_W4")
+             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD", "S2SR_TAIL_W4", "S2SR_D2H_STAGED")
 
 
 def engine(nb, precision=native.PREC_F16, **kw):
@@ -592,6 +592,29 @@ def test_tail_convs_one_wave_per_simd_form_gives_the_same_bytes(monkeypatch, gol
     for a, b in zip(outs["0"], outs["1"]):
         assert np.array_equal(a, b), float(np.abs(a - b).max())
     assert float(np.abs(outs["1"][2] - g4["y_b6"]).max()) <= TOL_HP
+
+
+def test_staged_device_to_host_bands_give_the_same_image(monkeypatch):
+    """s2sr_enhance_u8 / s2sr_forward_batch_u8 bring bands of 64 MB and more to the caller through two pinned 32-MB slices
+    (engine.hip d2h_staged; S2SR_D2H_STAGED=0 hands the caller's buffer to hipMemcpyAsync).  A 1248 x 1216 image at 256/10
+    (25 windows, chunks of unequal size, a 73-MB output with a band above the threshold and a last slice that is not full)
+    and a batch of 40 tiles (groups of 16: two 50-MB bands staged, the last one direct): both routes give the same bytes, and the image equals the windows pasted by hand."""
+    rng = np.random.default_rng(91)
+    img = rng.integers(0, 256, (1248, 1216, 3), dtype=np.uint8)
+    tiles = rng.integers(0, 256, (40, 256, 256, 3), dtype=np.uint8)
+    outs = {}
+    for staged in ("1", "0"):
+        e = _fresh(monkeypatch, 1, native.PREC_F16_HP, {"S2SR_D2H_STAGED": staged})
+        outs[staged] = (e.enhance_u8(img, tile=256, pad=10), e.forward_batch_u8(tiles))
+        if staged == "1":
+            wins = native.plan_tiles(1248, 1216, 256, 10)
+            srw = e.forward_batch_u8(np.stack([img[w.y1:w.y2, w.x1:w.x2] for w in wins]))
+            want = np.zeros_like(outs["1"][0])
+            for w, t in zip(wins, srw):
+                want[w.oy1:w.oy2, w.ox1:w.ox2] = t[w.crop_top:t.shape[0] - w.crop_bottom, w.crop_left:t.shape[1] - w.crop_right]
+        e.close()
+    assert np.array_equal(outs["1"][0], outs["0"][0]) and np.array_equal(outs["1"][1], outs["0"][1])
+    assert np.array_equal(outs["1"][0], want)
 
 
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
