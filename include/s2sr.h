@@ -98,6 +98,13 @@ int  s2sr_create(const s2sr_config* cfg, s2sr_handle** out);
 void s2sr_destroy(s2sr_handle* h);
 const char* s2sr_last_error(const s2sr_handle* h);   /* h may be NULL: last create() error */
 
+/* Page-locked host memory for images that cross PCIe.  The reference returns `output.cpu().numpy()` (cnn_super_resolution.py:231-233),
+ * a pageable array; a destination from s2sr_host_alloc lets s2sr_enhance_u8 / s2sr_forward_batch_u8 land their bands with the DMA
+ * engines (no staging copy, no first-touch page faults: 805 MB in 20 ms instead of 130).  Any host pointer stays valid as a
+ * destination; the library detects page-locked ones (hipPointerGetAttributes).  Not tied to a handle or device. */
+int  s2sr_host_alloc(size_t bytes, void** out);
+int  s2sr_host_free(void* p);
+
 /* replaces load_state_dict (cnn_super_resolution.py:205-213).  `blob`: for every conv in
  * registration order (conv_first, body.{b}.rdb{1..3}.conv{1..5}, conv_body, conv_up1,
  * conv_up2, conv_hr, conv_last): weight[Cout][Cin][3][3] then bias[Cout], fp32. */

@@ -989,7 +989,21 @@ int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, in
 static constexpr size_t kStageBytes = 32u << 20;
 // `exposed`: nothing computes under this copy (the last band, or the only one): below 128 MB the runtime's own path is then as
 // fast or faster (50 MB: 58.1 vs 60.3 ms per 1024 x 1024 call), and there are no conv workgroups for its copy kernels to displace.
+static bool is_pinned_host(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // an ordinary malloc'd pointer is "invalid value" to the runtime: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t bytes, bool exposed) {
+    if (is_pinned_host(dst)) {   // s2sr_host_alloc'd (or registered) destination: one DMA, nothing for this thread to copy
+        HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
+        HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+        return S2SR_OK;
+    }
     if (!h->d2h_staged_on || bytes < (exposed ? (128u << 20) : (24u << 20))) {
         HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->copy_stream));
         HIPCHK(h, hipStreamSynchronize(h->copy_stream));
@@ -1011,6 +1025,26 @@ static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t b
             HIPCHK(h, hipMemcpyAsync(h->stage_buf[i], src + k * kStageBytes, len(k), hipMemcpyDeviceToHost, h->copy_stream));
             HIPCHK(h, hipEventRecord(h->stage_ev[i], h->copy_stream));
         }
+    }
+    return S2SR_OK;
+}
+
+int s2sr_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return S2SR_E_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return S2SR_E_HIP;
+    }
+    return S2SR_OK;
+}
+
+int s2sr_host_free(void* p) {
+    if (!p) return S2SR_OK;
+    if (hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return S2SR_E_HIP;
     }
     return S2SR_OK;
 }

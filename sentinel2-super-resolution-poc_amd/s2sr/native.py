@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from pathlib import Path
 from typing import List, Optional
 
@@ -72,6 +73,8 @@ _PROTOS = {
     "s2sr_create": (C.c_int, [C.POINTER(_Config), C.POINTER(C.c_void_p)]),
     "s2sr_destroy": (None, [C.c_void_p]),
     "s2sr_last_error": (C.c_char_p, [C.c_void_p]),
+    "s2sr_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "s2sr_host_free": (C.c_int, [C.c_void_p]),
     "s2sr_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "s2sr_expected_blob_floats": (C.c_size_t, [C.c_int32]),
     "s2sr_load_weights_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -200,6 +203,68 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _PinnedPool:
+    """Page-locked output arrays (s2sr_host_alloc).  `RealESRGAN.enhance` returns a fresh numpy array per call
+    (cnn_super_resolution.py:231-233); a fresh pageable array costs the device-to-host path a staging copy and a page fault per
+    4 KB (805 MB: 130 ms), a page-locked one is filled by the DMA engines (20 ms).  Pinning is slow, so buffers are recycled:
+    an array handed out here returns its buffer to the pool when the last view of it is garbage collected; at most
+    S2SR_PINNED_POOL_MB (default 4096) of idle buffers are kept.  S2SR_PINNED_OUT=0 turns it off (plain np.empty)."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._free = {}          # nbytes -> [address, ...]
+        self._idle = 0
+        self._cap = int(os.environ.get("S2SR_PINNED_POOL_MB", "4096")) << 20
+        self.on = os.environ.get("S2SR_PINNED_OUT", "1") != "0"
+        self.hits = self.misses = 0
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        if not self.on or n < (8 << 20):
+            return np.empty(shape, dtype=dtype)
+        lib = load_library()
+        with self._lock:
+            lst = self._free.get(n)
+            addr = lst.pop() if lst else None
+            if addr is not None:
+                self._idle -= n
+                self.hits += 1
+        if addr is None:
+            p = C.c_void_p()
+            if lib.s2sr_host_alloc(n, C.byref(p)) or not p.value:
+                return np.empty(shape, dtype=dtype)      # no page-locked memory to be had: the pageable route still works
+            addr = p.value
+            self.misses += 1
+        buf = (C.c_uint8 * n).from_address(addr)
+        weakref.finalize(buf, self._give, addr, n)        # runs when the last numpy view of `buf` is gone
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _give(self, addr, n):
+        with self._lock:
+            if self._idle + n <= self._cap:
+                self._free.setdefault(n, []).append(addr)
+                self._idle += n
+                return
+        try:
+            load_library().s2sr_host_free(C.c_void_p(addr))
+        except Exception:
+            pass
+
+    def trim(self):
+        """Release every idle buffer."""
+        with self._lock:
+            addrs = [a for lst in self._free.values() for a in lst]
+            self._free.clear()
+            self._idle = 0
+        for a in addrs:
+            load_library().s2sr_host_free(C.c_void_p(a))
+
+
+pinned_pool = _PinnedPool()
+
+
 class Engine:
     """One native handle == one GPU.  Thread-safe (the library serialises calls per handle)."""
 
@@ -258,7 +323,7 @@ class Engine:
         tiles = np.ascontiguousarray(tiles, dtype=np.uint8)
         B, h, w, c = tiles.shape
         assert c == 3
-        out = np.empty((B, 4 * h, 4 * w, 3), dtype=np.uint8)
+        out = pinned_pool.empty((B, 4 * h, 4 * w, 3), np.uint8)
         self._check(self._lib.s2sr_forward_batch_u8(self._h, _ptr(tiles), B, h, w, _ptr(out)), "s2sr_forward_batch_u8")
         return out
 
@@ -279,7 +344,7 @@ class Engine:
         img = np.ascontiguousarray(img, dtype=np.uint8)
         H, W, c = img.shape
         assert c == 3
-        out = np.empty((4 * H, 4 * W, 3), dtype=np.uint8)
+        out = pinned_pool.empty((4 * H, 4 * W, 3), np.uint8)
         self._check(self._lib.s2sr_enhance_u8(self._h, _ptr(img), H, W, tile, pad, _ptr(out)), "s2sr_enhance_u8")
         return out
 

@@ -617,6 +617,42 @@ def test_staged_device_to_host_bands_give_the_same_image(monkeypatch):
     assert np.array_equal(outs["1"][0], want)
 
 
+def test_page_locked_outputs_are_recycled_and_equal_the_pageable_route():
+    """native.pinned_pool: outputs of 8 MB and more are numpy views of s2sr_host_alloc'd memory (the library then lands the
+    bands with one DMA each instead of staging); the buffer goes back to the pool when the last view dies and the next call
+    of that size reuses it.  Same bytes as with a pageable np.empty destination; the array is an ordinary writable ndarray."""
+    import gc
+    e = engine(1, native.PREC_F16_HP)
+    rng = np.random.default_rng(92)
+    img = rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)
+    pool = native.pinned_pool
+    assert pool.on
+    pool.trim()
+    h0, m0 = pool.hits, pool.misses
+    a = e.enhance_u8(img, tile=256, pad=10)
+    assert pool.misses == m0 + 1 and a.flags.writeable and a.shape == (2800, 3600, 3)
+    keep = a[100:110].copy()
+    view = a[100:110]
+    del a
+    gc.collect()
+    b = e.enhance_u8(img, tile=256, pad=10)          # `view` still pins the first buffer: a second one is allocated
+    assert pool.misses == m0 + 2 and np.array_equal(b[100:110], keep)
+    del view
+    gc.collect()
+    c = e.enhance_u8(img, tile=256, pad=10)          # ... and now the first one comes back
+    assert pool.hits == h0 + 1 and np.array_equal(c, b)
+    pool.on = False
+    try:
+        d = e.enhance_u8(img, tile=256, pad=10)
+    finally:
+        pool.on = True
+    assert np.array_equal(d, c)
+    c[0, 0, 0] ^= 1                                   # writable like any ndarray
+    del b, c
+    gc.collect()
+    pool.trim()
+
+
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
     """S2SR_TRUNK=0 keeps the RDB convs on the 8-wave kernel (conv3x3.hip EPI_RDB5 / EPI_RDB5_RRDB epilogues, fp16 lo,
     3-buffer workspace): the g3 / g4 / g5 goldens in HP and fast mode through a handle created with the switch set."""
