@@ -232,7 +232,7 @@ typedef struct s2sr_debug_config {
     int32_t fp8_hp_tail;    /* S2SR_FP8_TAIL=hp */
     int32_t graphs_on;      /* S2SR_GRAPH */
     int32_t trunk_wino;     /* 1: fp16 RDB conv1-4 in the row-Winograd F(2,3) form (S2SR_WINO) */
-    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC); [1]: fp16 conv1-4 loader-wave form (S2SR_F16_LOADER); [2]: conv_last folded 6-stage form (S2SR_LAST_FOLD); [3]: 4-wave tail convs (S2SR_TAIL_W4) */
+    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC); [1]: fp16 conv1-4 loader-wave form (S2SR_F16_LOADER); [2]: conv_last folded 6-stage form (S2SR_LAST_FOLD); [3]: 4-wave tail convs (S2SR_TAIL_W4); [4]: whole-patch fp16 conv1-4 forms allowed (S2SR_F16_FULL) */
 } s2sr_debug_config;
 int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
 

@@ -143,6 +143,7 @@ struct s2sr_handle {
     int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
     bool tail_w4 = false;         // S2SR_TAIL_W4=1: split-operand tail convs (up1, up2, hr, last) as 4 waves x twice the rows (one wave per SIMD)
     bool last_fold = true;        // S2SR_LAST_FOLD=0: conv_last (hp) reads all four e4m3 planes (8 stages) instead of folding w_lo into idle couts
+    bool f16_full = true;         // S2SR_F16_FULL=0: fp16 conv1-4 never take the whole-patch form (no px_live arithmetic in the epilogue) on 32-multiple launches
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
@@ -361,7 +362,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
         return S2SR_OK;
     }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
-        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2);
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4);
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
         if (e != hipErrorNotSupported) HIPCHK(h, e);
@@ -745,6 +746,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_MOSAIC_KX")) h->mosaic_kx = atoi(g);
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_F16_FULL")) h->f16_full = atoi(g) != 0;
     if (const char* g = getenv("S2SR_LAST_FOLD")) h->last_fold = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TAIL_W4")) h->tail_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_D2H_STAGED")) h->d2h_staged_on = atoi(g) != 0;
@@ -1658,7 +1660,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0; out->reserved[4] = h->f16_full ? 1 : 0;
     return S2SR_OK;
 }
 
@@ -1917,7 +1919,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     }
     auto launch_one = [&](bool tr) -> hipError_t {
         if (wino) return launch_conv_trunk_wino(p, st);           // stamps whenever p.trace is set
-        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2);
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4);
         if (h->trunk_w4) {
             const hipError_t e = launch_conv_trunk(p, ct, epi, st, tr);
             if (e != hipErrorNotSupported) return e;

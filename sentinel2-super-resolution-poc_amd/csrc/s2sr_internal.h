@@ -115,7 +115,8 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool upsample, bool
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st);   // stamped diagnostic build
 // the RRDB trunk convs as one-wave-per-SIMD workgroups (conv_trunk.hip): ct 1 + EPI_LRELU (conv1..4), ct 2 + EPI_RDB5 /
 // EPI_RDB5_RRDB (conv5).  hipErrorNotSupported = not a trunk form / launch too small: use launch_conv.
-// force_form (conv1-4 only; the per-layer parity hook): 0 = by launch size, 1 = 16x32 patches / 5-deep ring, 2 = 32x32 patches / 3-deep ring
+// force_form (conv1-4 only; the per-layer parity hook): 0 = by launch size, 1 = 16x32 patches / 5-deep ring, 2 = 32x32 patches / 3-deep ring,
+// 4 = loader wave, 5 = 8x32 patches, 6 / 7 / 8 = the whole-patch (FULL) forms of 2 / 1 / 5
 hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace = false, int force_form = 0);
 // fp16 RDB conv1..4 in the row-Winograd F(2,3) form (conv_wino.hip): weights transformed over dy (4 x 3 fragments per 16-channel
 // stage instead of 3 x 3), inputs transformed over 4 consecutive slab rows in registers, 12 MFMAs per 2 output rows instead of 18

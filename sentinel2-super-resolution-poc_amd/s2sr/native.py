@@ -465,6 +465,7 @@ def _debug_config(self) -> dict:
     d["f16_loader"] = int(c.reserved[1])
     d["last_fold"] = int(c.reserved[2])
     d["tail_w4"] = int(c.reserved[3])
+    d["f16_full"] = int(c.reserved[4])
     return d
 
 

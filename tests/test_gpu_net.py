@@ -29,7 +29,7 @@ _ENG = {}
 
 
 _SWITCHES = ("S2SR_SMALL8", "S2SR_F16_LOADER", "S2SR_MOSAIC", "S2SR_LO_EXP", "S2SR_TRUNK", "S2SR_FP8_LOADER", "S2SR_FP8_WSTREAM", "S2SR_FP8_W8", "S2SR_WINO", "S2SR_FP8_TAIL",
-             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD", "S2SR_TAIL_W4", "S2SR_D2H_STAGED")
+             "S2SR_FP8_XEXP", "S2SR_FP8_GEXP", "S2SR_NO_SUBPIXEL", "S2SR_GRAPH", "S2SR_LAST_FOLD", "S2SR_TAIL_W4", "S2SR_D2H_STAGED", "S2SR_F16_FULL")
 
 
 def engine(nb, precision=native.PREC_F16, **kw):
@@ -651,6 +651,24 @@ def test_page_locked_outputs_are_recycled_and_equal_the_pageable_route():
     del b, c
     gc.collect()
     pool.trim()
+
+
+def test_whole_patch_conv_forms_change_no_byte(monkeypatch):
+    """Launches without ragged edges or mosaics (256x256 tile batches, single tiles, 64x64 images) run the fp16 conv1-4 in
+    their whole-patch forms (conv_trunk_f16<..., FULL>); S2SR_F16_FULL=0 keeps the generic forms.  Same bytes for a batch
+    (32x32 patches), one tile (8x32 patches) and a 96x64 image (16x32 patches), 6 blocks, HP and fast mode."""
+    from s2sr.synth import synthetic_tiles
+    tiles = synthetic_tiles(12, 256, seed=77)
+    small = synthetic_tiles(2, 256, seed=78)[:, :96, :64]
+    for prec in (native.PREC_F16_HP, native.PREC_F16):
+        outs = {}
+        for full in ("1", "0"):
+            e = _fresh(monkeypatch, 6, prec, {"S2SR_F16_FULL": full})
+            assert e.debug_config()["f16_full"] == int(full)
+            outs[full] = (e.forward_batch_u8(tiles), e.forward_batch_u8(tiles[:1]), e.forward_batch_u8(np.ascontiguousarray(small)))
+            e.close()
+        for a, b in zip(outs["1"], outs["0"]):
+            assert np.array_equal(a, b)
 
 
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):

@@ -104,6 +104,32 @@ def test_f16_conv14_integer_layout(eng, form):
         assert np.array_equal(y, _conv64(x, w, np.zeros(32, np.float32)).astype(np.float32)), (t, form)
 
 
+@pytest.mark.parametrize("form,base", [(6, 2), (7, 1), (8, 5)])
+def test_f16_conv14_whole_patch_forms(eng, form, base):
+    """Forms 6 / 7 / 8: the 32x32 / 16x32 / 8x32 conv1-4 kernels compiled for launches without ragged edges or mosaic
+    separators (conv_trunk_f16<..., FULL>: no px_live arithmetic, no trash-line selects in the epilogue) -- what 256x256 tile
+    batches run.  Same bytes as the generic form on 32-multiple shapes, the exact-integer layout check, and a refusal
+    (not a wrong answer) when the shape is ragged."""
+    rng = np.random.default_rng(600 + form)
+    for Cin, N, H, W in ((64, 1, 32, 32), (96, 2, 64, 96), (160, 1, 96, 64), (128, 3, 32, 160)):
+        x, w, b = _rand(rng, N, Cin, 32, H, W)
+        y = _run14(eng, x, w, b, form)
+        assert np.array_equal(y, _run14(eng, x, w, b, base)), (form, Cin, H, W)
+        r = _lrelu(_conv64(x, w, b))
+        assert np.all(np.abs(y - r) <= 2e-4 * max(1.0, np.abs(r).max()) + np.abs(r) * 2.0 ** -11)
+    Cin, H, W = 160, 64, 64
+    x = rng.integers(-6, 7, size=(1, Cin, H, W)).astype(np.float32)
+    w = np.zeros((32, Cin, 3, 3), np.float32)
+    for c in range(32):
+        w[c, (c * 5 + 3) % Cin, ((c * 7) % 9) // 3, ((c * 7) % 9) % 3] = 1.0 if c % 3 else -2.0
+    b = rng.integers(-5, 6, size=32).astype(np.float32)
+    v = _conv64(x, w, b).astype(np.float32)
+    assert np.array_equal(_run14(eng, x, w, b, form), np.maximum(v, np.float32(0.2) * v).astype(np.float16).astype(np.float32))
+    x, w, b = _rand(rng, 1, 64, 32, 33, 45)
+    with pytest.raises(native.S2srError):
+        eng.debug_conv_trunk(K14, x, w, b, form=form)
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 16, 32), (1, 17, 70), (2, 33, 33)])
 def test_f16_conv5_random(eng, N, H, W):
     """conv5: v = 0.2 * (conv + b) + (x + lo), written as the (fp16 hi, e4m3(lo * 2^lo_exp)) pair; rdb3's conv5 adds
