@@ -200,8 +200,10 @@ __device__ __forceinline__ void wait_vm_barrier() {
 // (one parity per launch would write every other 32-B sector of each line: read-modify-write in L2/HBM).
 // The launch walks patches of the source image (p.H, p.W, sHp, sWp = source; Hp, Wp = the 2x output
 // tensor) and stores to (2y+py, 2x+q).
+// FULL: the launch has no ragged edge and no mosaic separators (whole patches only: H % TH == 0, W % 32 == 0, mos_py == 0): the
+// epilogue carries no px_live arithmetic and no trash-line selects (split-operand producers: conv_up -3.7 %, conv_hr -2.6 %).
 template <int CT, int NP, int WAVES, int EPI, bool UP, int R, bool TRACE = false, int HPO = 0, int OCC = 1, bool F8 = false,
-          int PH = -1>
+          int PH = -1, bool FULL = false>
 __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const ConvParams p) {
     using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
     static_assert(!F8 || R == 4, "the fp8 pair schedule is written for a 4-slot ring");
@@ -572,7 +574,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = px_live(p, y, x);
+            ok[np] = FULL ? true : px_live(p, y, x);
             opix[np] = PH >= 0 ? (size_t)(2 * y + PY + 1) * p.Wp + (2 * x + 1)    // sub-pixel form: row parity PY, column parity q added per tile
                                : (size_t)(y + 1) * p.Wp + (x + 1);
         }
@@ -985,12 +987,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
 // launch
 // ------------------------------------------------------------------------------------------
 template <int CT, int EPI, bool UP, int WAVES, int NP, int R, bool TRACE = false, int HPO = 0, int OCC = 1, bool F8 = false,
-          int PH = -1>
+          int PH = -1, bool FULL = false>
 static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     using G = Geom<WAVES, NP, CT, R, (PH >= 0 ? 4 : 9)>;
+    if (FULL && (p.mos_py != 0 || p.H % G::TH != 0 || p.W % G::TW != 0)) return hipErrorInvalidValue;
     static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
-    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH>;
+    auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH, FULL>;
     if (F8 && ((p.nstage != 8 && !(EPI == EPI_LAST && p.nstage == 6 && p.fold_lo)) || p.seg_len != 4 || !p.src_lo))
         return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes (conv_last folded: + 2)
     if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
@@ -1073,8 +1076,11 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
             if (ct == 2 && lo_out && epi == EPI_LRELU && !up) return launch_t<2, EPI_LRELU, false, 4, 4, 4, false, 1, 1, true>(p, st);
             if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 4, 4, 4, false, 0, 1, true>(p, st);
         }
+        const bool full = p.mos_py == 0 && p.H % 16 == 0 && p.W % 32 == 0 && !(p.tail_form & 8);   // whole 16x32 patches (bit 3: diagnostic off switch)
         if (ct == 2 && lo_out && epi == EPI_LRELU && !up && (p.tail_form & 2))   // conv_hr in front of a folded conv_last: no hi8 planes out
-            return launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true>(p, st);
+            return full ? launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true, -1, true>(p, st)
+                        : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true>(p, st);
+        if (ct == 2 && lo_out && epi == EPI_BODY && !up && full) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true, -1, true>(p, st);
         if (ct == 2 && lo_out) {
             if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, 1, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 1, 1, true>(p, st);
             if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true>(p, st);
@@ -1104,6 +1110,10 @@ hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f
     if (f8 && (p.tail_form & 1)) {   // one wave per SIMD: 4 waves x 2 source rows
         if (py == 0) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 0>(p, st);
         if (py == 1) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 1>(p, st);
+    }
+    if (f8 && p.mos_py == 0 && p.H % 8 == 0 && p.W % 32 == 0 && !(p.tail_form & 8)) {   // whole 8x32 source patches
+        if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 0, true>(p, st);
+        if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 1, true>(p, st);
     }
     if (f8) {
         if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 0>(p, st);

@@ -342,7 +342,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     p.seg_len = cw.seg_len;
     p.seg_lo_mask = cw.seg_lo_mask;
     p.fold_lo = cw.fold ? 1 : 0;
-    p.tail_form = h->tail_w4 ? 1 : 0;
+    p.tail_form = (h->tail_w4 ? 1 : 0) | (h->f16_full ? 0 : 8);
     // conv_hr: a folded conv_last (the last conv) reads x_lo planes only, so the e4m3(x_hi) planes need not be written
     if (fam == F_HR && lo_out && !h->convs.empty() && h->convs.back().f8 && h->convs.back().fold) p.tail_form |= 2;
     p.trash = h->d_trash;
@@ -378,7 +378,7 @@ int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams 
                     int oHp, int oWp) {
     p.N = n; p.H = Hs; p.W = Ws; p.sHp = sHp; p.sWp = sWp; p.Hp = oHp; p.Wp = oWp;
     p.bias = cw.d_bias; p.nstage = cw.f8 ? 8 : 4; p.seg_len = 4; p.seg_lo_mask = cw.f8 ? 0x2 : 0x0; p.fold_lo = 0;
-    p.tail_form = h->tail_w4 ? 1 : 0;
+    p.tail_form = (h->tail_w4 ? 1 : 0) | (h->f16_full ? 0 : 8);
     p.trash = h->d_trash;
     const double px = (double)n * Hs * Ws;
     for (int k = 0; k < 2; ++k) {

@@ -87,7 +87,7 @@ struct ConvParams {
                              // streamed, 2 all resident), bit 3 two waves per SIMD -- from S2SR_FP8_LOADER / _WSTREAM / _W8 at s2sr_create
     int32_t f16_form;        // conv_trunk_f16 conv1-4 kernel form: bit 0 = 32x32 patches with the load-only fifth wave (S2SR_F16_LOADER), bit 1 = single
                              // tiles keep the 16x32-patch form instead of 8x32 (S2SR_SMALL8=0)
-    int32_t tail_form;       // split-operand head/tail convs (conv3x3.hip F8 schedule): bit 0 = one wave per SIMD (4 waves, twice the rows per wave; S2SR_TAIL_W4), bit 1 = this conv's consumer reads no e4m3(x_hi) planes (conv_hr before a folded conv_last): do not write them
+    int32_t tail_form;       // split-operand head/tail convs (conv3x3.hip F8 schedule): bit 0 = one wave per SIMD (4 waves, twice the rows per wave; S2SR_TAIL_W4), bit 1 = this conv's consumer reads no e4m3(x_hi) planes (conv_hr before a folded conv_last): do not write them, bit 3 = never the whole-patch (FULL) forms (S2SR_F16_FULL=0)
     int32_t lo_exp;          // conv_trunk_f16 conv5: the trunk's lo half is stored as e4m3(lo * 2^lo_exp) planes (xh_in, T, lo_skip)
     // Window mosaics (the AOI path, engine.hip forward_dev): equal-size windows of `_tile_process` (cnn_super_resolution.py:249-257) laid
     // out on a grid inside ONE image with a single zero row / column between neighbours -- the conv zero padding of both, at
