@@ -569,12 +569,13 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
         const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
         const int y0 = ty * G::TH, x0 = tx * G::TW;
         const int x = x0 + pcol;
+        const PatchLive pl = patch_live(p, y0, x0);
         bool ok[NP];
         size_t opix[NP];
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = FULL ? true : px_live(p, y, x);
+            ok[np] = FULL ? true : px_live(p, pl, y0, x0, y, x);
             opix[np] = PH >= 0 ? (size_t)(2 * y + PY + 1) * p.Wp + (2 * x + 1)    // sub-pixel form: row parity PY, column parity q added per tile
                                : (size_t)(y + 1) * p.Wp + (x + 1);
         }

@@ -605,12 +605,13 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = kTrunk ? v[i] * 0.2f : v[i];
             }
+        const PatchLive pl = patch_live(p, y0, x0);
         bool ok[NP];
         size_t opix[NP];
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = FULL ? true : px_live(p, y, x);
+            ok[np] = FULL ? true : px_live(p, pl, y0, x0, y, x);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t ln = (size_t)n * 2 * oblk;   // image offset inside the e4m3 lo tensors, bytes
@@ -1325,12 +1326,13 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = kTrunk ? v[i] * 0.2f : v[i];
             }
+        const PatchLive pl = patch_live(p, y0, x0);
         bool ok[NP];
         size_t opix[NP];
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const int y = y0 + wave * NP + np;
-            ok[np] = px_live(p, y, x);
+            ok[np] = px_live(p, pl, y0, x0, y, x);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
         const size_t xn = (size_t)n * p.xh_img;

@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
         const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
         const int y0 = ty * G::TH, x0 = tx * G::TW;
         const int x = x0 + pcol;
+        const PatchLive pl = patch_live(p, y0, x0);
         f32x16 bv;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(256, 1) conv_wino_f16(const ConvParams p) {
             for (int j = 0; j < 2; ++j) {
                 const int np = 2 * t + j;
                 const int y = y0 + wave * NP + np;
-                const bool ok = px_live(p, y, x);
+                const bool ok = px_live(p, pl, y0, x0, y, x);
                 const size_t opix = (size_t)(y + 1) * p.Wp + (x + 1);
                 u32x2 hpk[4];
 #pragma unroll

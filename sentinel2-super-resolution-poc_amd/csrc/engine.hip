@@ -402,6 +402,7 @@ int run_net(s2sr_handle* h, hipStream_t st, int n, int H, int W, float* d_out_f3
     auto mosaic_at = [&](ConvParams& q, int scale) {
         if (!mo.on()) return;
         q.mos_py = (mo.wh + 1) * scale; q.mos_ry = mo.wh * scale; q.mos_px = (mo.ww + 1) * scale; q.mos_rx = mo.ww * scale;
+        q.mos_my = (uint32_t)(0x100000000ull / (uint32_t)q.mos_py) + 1u; q.mos_mx = (uint32_t)(0x100000000ull / (uint32_t)q.mos_px) + 1u;
         q.mos_kx = mo.kx; q.mos_ky = mo.ky; q.mos_count = mo.count;
     };
     ConvParams b{};

@@ -95,6 +95,7 @@ struct ConvParams {
     // (y, x) is live iff y % mos_py < mos_ry and x % mos_px < mos_rx (period = window + 1, real extent = window).  0 = off.
     // 276-pixel windows then cost 280 x 280 of patch area instead of 288 x 288.
     int32_t mos_py, mos_ry, mos_px, mos_rx;
+    uint32_t mos_my, mos_mx;             // floor(2^32 / mos_py) + 1, floor(2^32 / mos_px) + 1 (patch_live); 0: take the modulo route
     int32_t mos_kx, mos_ky, mos_count;   // EPI_LAST: grid of a mosaic and the number of windows in this launch: window t = (n * ky + wy) * kx + wx
                                          // is written as image t of [count, ry, rx]; slots past the count are not written
     char* trash;             // >= 4 KiB scratch: out-of-image lanes park their (unconditional) stores here
@@ -107,6 +108,34 @@ struct ConvParams {
 __device__ __forceinline__ bool px_live(const ConvParams& p, int y, int x) {
     bool ok = (y < p.H) && (x < p.W);
     if (p.mos_py) ok = ok && (y % p.mos_py < p.mos_ry) && (x % p.mos_px < p.mos_rx);
+    return ok;
+}
+// The same predicate for the pixels of ONE patch (first row y0, first column x0, at most 32 x 32) without a division per row
+// and lane: the residues of y0 and x0 are taken once per patch (wave-uniform; multiply-high by the host's 2^32 / period, exact
+// for coordinates below 65536), a pixel's residue is that plus its offset, wrapped at most once (periods of 32 and more;
+// shorter periods -- toy windows in tests -- take the modulo route).
+struct PatchLive { int ry0, rx0; bool fast; };
+__device__ __forceinline__ PatchLive patch_live(const ConvParams& p, int y0, int x0) {
+    PatchLive L{0, 0, false};
+    if (p.mos_py && p.mos_py >= 32 && p.mos_px >= 32 && p.mos_my) {
+        L.fast = true;
+        L.ry0 = y0 - (int)__umulhi((uint32_t)y0, (uint32_t)p.mos_my) * p.mos_py;
+        L.rx0 = x0 - (int)__umulhi((uint32_t)x0, (uint32_t)p.mos_mx) * p.mos_px;
+    }
+    return L;
+}
+__device__ __forceinline__ bool px_live(const ConvParams& p, const PatchLive& L, int y0, int x0, int y, int x) {
+    bool ok = (y < p.H) && (x < p.W);
+    if (p.mos_py) {
+        if (L.fast) {
+            int a = L.ry0 + (y - y0), b = L.rx0 + (x - x0);
+            a = a >= p.mos_py ? a - p.mos_py : a;
+            b = b >= p.mos_px ? b - p.mos_px : b;
+            ok = ok && a < p.mos_ry && b < p.mos_rx;
+        } else {
+            ok = ok && (y % p.mos_py < p.mos_ry) && (x % p.mos_px < p.mos_rx);
+        }
+    }
     return ok;
 }
 
