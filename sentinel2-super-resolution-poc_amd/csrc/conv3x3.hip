@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
     static_assert(!F8 || R == 4, "the fp8 pair schedule is written for a 4-slot ring");
     static_assert(PH < 0 || (!UP && CT % 2 == 0 && R == 4), "the sub-pixel form replaces upsample-on-load");
     constexpr int PY = PH >= 0 ? PH : 0;
+    // conv_last (F8): HPO == 3 names the folded 6-stage schedule (S2SR_LAST_FOLD, default) and compiles only that; HPO == 0 only the
+    // 8-stage one.  One kernel carrying both needed 1,479 SGPR-spill reloads per trip (it writes no planes: HPO is free to mean this).
+    constexpr bool kFold6 = F8 && EPI == EPI_LAST && HPO == 3;
     constexpr int CTR = PH >= 0 ? CT / 2 : CT;     // real cout tiles; in the sub-pixel form tile ct = q*CTR + rc, q = column parity
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                         size_t oimg = (size_t)n;
                         int oy = y, ox = x, oH = p.H, oW = p.W;
                         bool live = ok[np];
-                        if (p.mos_py) {
+                        if (!FULL && p.mos_py) {
                             const int wy = y / p.mos_py, wx = x / p.mos_px;
                             const int t = (n * p.mos_ky + wy) * p.mos_kx + wx;
                             live = live && t < p.mos_count;
@@ -687,7 +690,7 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
                             uint32_t P = 0;
 #pragma unroll
                             for (int i = 0; i < 3; ++i) {
-                                o3[i] = p.fold_lo ? __fadd_rn(v[i], acc[ct][np][4 + i]) : v[i];   // + x*w_lo (couts 8..)
+                                o3[i] = (kFold6 || (!F8 && p.fold_lo)) ? __fadd_rn(v[i], acc[ct][np][4 + i]) : v[i];   // + x*w_lo (couts 8..)
                                 // (out*255).clip(0,255).astype(uint8): truncation (cnn_super_resolution.py:232)
                                 const float q = fminf(fmaxf(__fmul_rn(o3[i], 255.0f), 0.f), 255.f);
                                 P |= (uint32_t)(int)q << (8 * i);
@@ -884,12 +887,12 @@ __global__ void __launch_bounds__(WAVES * 64, OCC * WAVES / 4) conv3x3_f16(const
             issued += n;
             return n;
         };
-        if constexpr (EPI == EPI_LAST) {
+        if constexpr (kFold6) {
             // conv_last, folded form (p.nstage == 6): w_lo rides in the idle couts 8.. of the fp16 stages, so the
             // x_hi planes never come in as e4m3 -- a patch is 4 fp16 stages + ONE pair (x_lo planes against w_hi).
             // Six stages on a four-slot ring: stage j sits in slot j & 3, so patches alternate between
             // "fp16 in slots 0..3, pair in (0,1)" and "fp16 in slots 2,3,0,1, pair in (2,3)".
-            if (NS == 6) {
+            {
                 while (k < S) {
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
@@ -995,7 +998,7 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
     static_assert(G::LDS_BYTES * OCC <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::PW*(R - 2) < 64, "vmcnt field is 6 bits");
     auto kern = conv3x3_f16<CT, NP, WAVES, EPI, UP, R, TRACE, HPO, OCC, F8, PH, FULL>;
-    if (F8 && ((p.nstage != 8 && !(EPI == EPI_LAST && p.nstage == 6 && p.fold_lo)) || p.seg_len != 4 || !p.src_lo))
+    if (F8 && (p.nstage != ((EPI == EPI_LAST && HPO == 3) ? 6 : 8) || ((EPI == EPI_LAST && HPO == 3) && !p.fold_lo) || p.seg_len != 4 || !p.src_lo))
         return hipErrorInvalidValue;   // 4 fp16 blocks + 4 fp8 planes (conv_last folded: + 2)
     if (PH >= 0 && !F8 && p.nstage != 4) return hipErrorInvalidValue;
     if (EPI == EPI_LAST && (p.cout > 3 || CT != 1)) return hipErrorInvalidValue;   // its epilogue writes couts 0..2 (RGB) only
@@ -1075,7 +1078,7 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
     if (f8_in) {   // split-operand mode: fp16 main term + fp8 correction planes in; lo_out: fp8 planes out as well
         if (p.tail_form & 1) {   // one wave per SIMD: 4 waves x 4 rows, the same 16x32 patch and ring
             if (ct == 2 && lo_out && epi == EPI_LRELU && !up) return launch_t<2, EPI_LRELU, false, 4, 4, 4, false, 1, 1, true>(p, st);
-            if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 4, 4, 4, false, 0, 1, true>(p, st);
+            if (ct == 1 && !lo_out && epi == EPI_LAST && !up && p.nstage == 6 && p.fold_lo) return launch_t<1, EPI_LAST, false, 4, 4, 4, false, 3, 1, true>(p, st);
         }
         const bool full = p.mos_py == 0 && p.H % 16 == 0 && p.W % 32 == 0 && !(p.tail_form & 8);   // whole 16x32 patches (bit 3: diagnostic off switch)
         if (ct == 2 && lo_out && epi == EPI_LRELU && !up && (p.tail_form & 2))   // conv_hr in front of a folded conv_last: no hi8 planes out
@@ -1086,7 +1089,12 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
             if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, 1, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 1, 1, true>(p, st);
             if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true>(p, st);
         }
-        if (ct == 1 && !lo_out && epi == EPI_LAST && !up) return launch_t<1, EPI_LAST, false, 8, 2, 4, false, 0, 1, true>(p, st);
+        if (ct == 1 && !lo_out && epi == EPI_LAST && !up) {
+            if (p.nstage == 6 && p.fold_lo)
+                return full ? launch_t<1, EPI_LAST, false, 8, 2, 4, false, 3, 1, true, -1, true>(p, st)
+                            : launch_t<1, EPI_LAST, false, 8, 2, 4, false, 3, 1, true>(p, st);
+            return launch_t<1, EPI_LAST, false, 8, 2, 4, false, 0, 1, true>(p, st);
+        }
         return hipErrorInvalidValue;
     }
     if (lo_out) return hipErrorInvalidValue;
