@@ -236,6 +236,12 @@ typedef struct s2sr_debug_config {
 } s2sr_debug_config;
 int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
 
+/* The chunk plan of a tiled s2sr_enhance_u8 (host arithmetic only, no device needed): `units` row units of `unit_windows` windows
+ * each, at most `u_max` units per chunk, `per` windows per launch image (mosaic), `pimg` 32x32 patches per launch image, `ncu`
+ * workgroups.  Writes the chunk sizes front to back; *n = their number (cap 0: count only). */
+int  s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, int32_t per, int32_t pimg, int32_t ncu,
+                            int32_t* sizes, int32_t cap, int32_t* n);
+
 /* test hook: ONE RDB-shaped conv through the TRUNK kernels (conv_trunk.hip: conv_trunk_f16 / conv_trunk_f8), host tensors in
  * NCHW fp32 -- the per-layer parity check of the kernels that carry 84 % of a step (s2sr_debug_conv goes through conv3x3.hip).
  *   kind 0: fp16 conv1-4 form   y = lrelu(conv(x) + b)                        Cin in {64,96,128,160}, Cout 32, y = the fp16 plane written

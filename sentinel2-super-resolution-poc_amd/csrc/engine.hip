@@ -1123,6 +1123,49 @@ static void build_stitch_maps(const std::vector<s2sr_window>& wins, int nx, int 
 }
 
 // RealESRGAN.enhance (cnn_super_resolution.py:217-234) incl. _tile_process (:236-280)
+// Chunk sizes of a tiled enhance(), front to back, in row units (pure host arithmetic; s2sr_debug_plan_chunks exposes it to the
+// CPU tests).  `unit_windows` windows per row unit, `per` windows per launch image (a mosaic; 1 without), `pimg` 32 x 32 patches per
+// launch image, `ncu` persistent workgroups.  The tail (last, middle) is searched for the fewest trunk-conv rounds plus the
+// exposed copy of the last band; what is left goes in front in pieces of at most u_max units.
+static void plan_chunk_sizes(int units, int u_max, long unit_windows, int per, long pimg, int ncu, std::vector<int>& sizes) {
+    sizes.clear();
+    if (units <= 0) return;
+    if (u_max < 1) u_max = 1;
+    if (per < 1) per = 1;
+    if (ncu < 1) ncu = 1;
+    auto rounds = [&](int u) -> double {                                        // trunk-conv rounds of a chunk of u units
+        const long imgs = ((long)u * unit_windows + per - 1) / per;
+        return (double)((imgs * pimg + ncu - 1) / ncu);
+    };
+    const double copy_per_unit = (double)unit_windows * pimg / per / ncu / 6.0;  // exposed copy of one unit, in rounds
+    int best_last = 1, best_mid = 0;
+    double best = 1e300;
+    for (int last = 1; last <= 3 && last <= units; ++last)
+        for (int mid = 0; mid <= 12 && last + mid <= units; ++mid) {
+            if (mid > u_max || last > u_max || mid > 5 * last) continue;         // a band's copy must fit under the next chunk's compute (~6x)
+            const int front = units - last - mid;
+            if (front > 0 && mid == 0 && front > 5 * last) continue;            // a big chunk straight in front of the last one
+            if (front > 0 && mid > 0 && front > 6 * mid && front <= u_max) continue;
+            double c = rounds(last) + (mid ? rounds(mid) : 0.0) + last * copy_per_unit;
+            for (int left = front; left > 0;) { const int u = left < u_max ? left : u_max; c += rounds(u); left -= u; }
+            if (c < best - 1e-9) { best = c; best_last = last; best_mid = mid; }
+        }
+    for (int left = units - best_last - best_mid; left > 0;) { const int u = left < u_max ? left : u_max; sizes.push_back(u); left -= u; }
+    if (best_mid) sizes.push_back(best_mid);
+    sizes.push_back(best_last);
+}
+
+int s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, int32_t per, int32_t pimg, int32_t ncu, int32_t* sizes,
+                           int32_t cap, int32_t* n) {
+    if (!n || units < 0 || cap < 0 || (cap > 0 && !sizes)) return S2SR_E_INVALID;
+    std::vector<int> v;
+    plan_chunk_sizes(units, u_max, unit_windows, per, pimg, ncu, v);
+    *n = (int32_t)v.size();
+    if ((int)v.size() > cap) return cap == 0 ? S2SR_OK : S2SR_E_CAPACITY;
+    for (size_t i = 0; i < v.size(); ++i) sizes[i] = v[i];
+    return S2SR_OK;
+}
+
 static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int tile, int pad, uint8_t* out_u8,
                         float* out_f32, bool force_tiled = false) {
     if (!h || !img || (!out_u8 && !out_f32) || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
@@ -1212,7 +1255,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         // windows is 1225 patches = 4.8 per CU, five rounds for 4.8 rounds of work; five mosaics are 23.9 -> 24).
         // Chunk sizes.  The device-to-host copy of a chunk's band hides under the NEXT chunk's compute and only the last band's
         // copy is exposed, so chunks shrink towards the end (a row of 276-pixel windows computes ~6x longer than its 13 MB band
-        // takes to reach pageable host memory; a chunk may be up to 4x its successor).  What a small chunk costs is the rounding
+        // takes to reach pageable host memory; a chunk may be up to 5x its successor).  What a small chunk costs is the rounding
         // of its patch count to whole rounds of the persistent workgroups in the trunk convs (32 x 32 patches; a 4 x 4 mosaic
         // of 276-pixel windows = 1225 patches = 4.8 rounds of 256: 1, 2, 3, 4 mosaics lose 4.3 %, 5 or 10 lose 0.3 %).  The
         // tail (last, middle) is searched over small sizes for the fewest rounds + exposed copy; the rest goes in front in
@@ -1231,27 +1274,8 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
             const long pimg = mo.on() ? (long)((mo.ky * (wh + 1) - 1 + 31) / 32) * ((mo.kx * (ww + 1) - 1 + 31) / 32)
                                       : (long)((wh + 31) / 32) * ((ww + 31) / 32);      // 32 x 32 patches per launch image
-            auto rounds = [&](int u) -> double {                                        // trunk-conv rounds of a chunk of u units
-                const long imgs = ((long)u * r_min * nx + per - 1) / per;
-                return (double)((imgs * pimg + ncu - 1) / ncu);
-            };
-            const double copy_per_unit = (double)r_min * nx * pimg / per / ncu / 6.0;  // exposed copy of one unit, in rounds
-            int best_last = 1, best_mid = 0;
-            double best = 1e300;
-            for (int last = 1; last <= 3 && last <= units; ++last)
-                for (int mid = 0; mid <= 12 && last + mid <= units; ++mid) {
-                    if (mid > u_max || last > u_max || mid > 4 * last) continue;
-                    const int front = units - last - mid;
-                    if (front > 0 && mid == 0 && front > 4 * last) continue;            // a big chunk straight in front of the last one
-                    if (front > 0 && mid > 0 && front > 6 * mid && front <= u_max) continue;
-                    double c = rounds(last) + (mid ? rounds(mid) : 0.0) + last * copy_per_unit;
-                    for (int left = front; left > 0;) { const int u = left < u_max ? left : u_max; c += rounds(u); left -= u; }
-                    if (c < best - 1e-9) { best = c; best_last = last; best_mid = mid; }
-                }
             std::vector<int> sizes;                                                     // in units, front to back
-            for (int left = units - best_last - best_mid; left > 0;) { const int u = left < u_max ? left : u_max; sizes.push_back(u); left -= u; }
-            if (best_mid) sizes.push_back(best_mid);
-            sizes.push_back(best_last);
+            plan_chunk_sizes(units, u_max, r_min * nx, per, pimg, ncu, sizes);
             int r = 0;
             for (int u : sizes) { chunk_r0.push_back(r); r += u * r_min; }
             chunk_r0.push_back(ny);

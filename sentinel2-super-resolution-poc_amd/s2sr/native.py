@@ -109,6 +109,7 @@ _PROTOS = {
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
+    "s2sr_debug_plan_chunks": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_debug_get_config": (C.c_int, [C.c_void_p, C.POINTER(DebugConfig)]),
     "s2sr_debug_conv_trunk": (C.c_int, [C.c_void_p, C.POINTER(DebugTrunkArgs)]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
@@ -197,6 +198,17 @@ def plan_tiles(H: int, W: int, tile: int = 256, pad: int = 10, scale: int = 4) -
     if rc:
         raise S2srError(f"s2sr_plan_tiles: {_ERR.get(rc, rc)}")
     return list(arr)
+
+
+def plan_chunks(units: int, u_max: int, unit_windows: int, per: int, pimg: int, ncu: int = 256) -> List[int]:
+    """Chunk sizes (row units, front to back) s2sr_enhance_u8 would use; host arithmetic, works without a GPU."""
+    lib = load_library()
+    n = C.c_int32(0)
+    buf = (C.c_int32 * max(1, units))()
+    rc = lib.s2sr_debug_plan_chunks(units, u_max, unit_windows, per, pimg, ncu, buf, max(1, units), C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_debug_plan_chunks failed ({_ERR.get(rc, rc)})")
+    return [int(buf[i]) for i in range(n.value)]
 
 
 def _ptr(a: np.ndarray):

@@ -151,3 +151,28 @@ def test_hidden_asm_loads_are_not_touched_before_their_wait(tmp_path):
         assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:]
         if src != "conv_wino.hip":       # (the Winograd form has inline MFMAs but no hidden loads: only the wait-state check applies)
             assert asm.read_text().count("global_load_dwordx2 a[") + asm.read_text().count("global_load_dwordx4 a[") > 0
+
+
+def test_enhance_chunk_plan_properties():
+    """The chunk plan of a tiled s2sr_enhance_u8 (engine.hip plan_chunk_sizes through s2sr_debug_plan_chunks; host arithmetic,
+    no device): every row unit is covered once, no chunk exceeds the workspace limit, the last chunk (whose band copy is exposed)
+    is small, the middle piece is at most 5x the last, and the plan is the one the measurements
+    were made with -- 4096x4096 at 256/10 (16 row units of 16 windows, 4x4 mosaics of 1225 patches, 256 workgroups) goes as
+    10 + 5 + 1 (whole workgroup rounds: 48 + 24 + 5 of 76.6), 2048x2048 (4 units of 2 rows) as 3 + 1."""
+    from s2sr import native
+    assert native.plan_chunks(16, 16, 16, 16, 1225, 256) == [10, 5, 1]
+    assert native.plan_chunks(4, 4, 16, 16, 1225, 256) == [3, 1]
+    assert native.plan_chunks(1, 16, 16, 16, 1225, 256) == [1]
+    assert native.plan_chunks(0, 16, 16, 16, 1225, 256) == []
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        units = int(rng.integers(1, 200)); u_max = int(rng.integers(1, 40)); uw = int(rng.integers(1, 64))
+        per = int(rng.choice([1, 4, 8, 16, 64])); pimg = int(rng.integers(1, 5000)); ncu = int(rng.choice([64, 256, 304]))
+        sz = native.plan_chunks(units, u_max, uw, per, pimg, ncu)
+        assert sum(sz) == units and all(1 <= u <= u_max for u in sz), (units, u_max, sz)
+        assert sz[-1] <= 3
+        if len(sz) >= 2:
+            assert sz[-2] <= 5 * sz[-1] or sz[-2] == u_max or len(sz) == 2   # the middle piece is bounded by 5x the last (or it is a front piece)
+        # front pieces are as large as the workspace allows: at most one of them is not full
+        front = sz[:-2] if len(sz) > 2 else []
+        assert sum(1 for u in front if u != u_max) <= 1
