@@ -236,6 +236,9 @@ typedef struct s2sr_debug_config {
 } s2sr_debug_config;
 int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
 
+/* How `B` equal windows of th x tw travel through the net: kx x ky per launch image with one zero row / column between neighbours
+ * (1 x 1: one window per image -- sizes that are multiples of the 32-pixel patch gain nothing).  Host arithmetic only. */
+int  s2sr_debug_pick_mosaic(int32_t B, int32_t th, int32_t tw, int32_t* kx, int32_t* ky);
 /* The chunk plan of a tiled s2sr_enhance_u8 (host arithmetic only, no device needed): `units` row units of `unit_windows` windows
  * each, at most `u_max` units per chunk, `per` windows per launch image (mosaic), `pimg` 32x32 patches per launch image, `ncu`
  * workgroups.  Writes the chunk sizes front to back; *n = their number (cap 0: count only). */

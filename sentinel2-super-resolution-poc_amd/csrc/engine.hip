@@ -574,9 +574,12 @@ int group_size(const s2sr_handle* h, int B, int H, int W) {
 // area each, 9 % dead MFMA work) and there are several of them, kx x ky windows share one image with a zero row / column
 // between neighbours (ConvParams::mos_*): 4 x 4 windows of 276 -> 1107 x 1107 -> 1120 x 1120 of patch area, 280 per window.
 // Same bytes out: every output pixel accumulates the same products in the same order wherever its window sits.
-Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) {
+static Mosaic pick_mosaic_cfg(bool mosaic_on, int mosaic_kx, int B, int th, int tw);
+Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) { return pick_mosaic_cfg(h->mosaic_on, h->mosaic_kx, B, th, tw); }
+// pure host arithmetic (s2sr_debug_pick_mosaic exposes it to the CPU tests)
+static Mosaic pick_mosaic_cfg(bool mosaic_on, int mosaic_kx, int B, int th, int tw) {
     Mosaic m;
-    if (!h->mosaic_on || B < 2) return m;
+    if (!mosaic_on || B < 2) return m;
     const double waste = (double)roundup32(th) * roundup32(tw) / ((double)th * tw);
     if (waste < 1.03) return m;                       // 256 x 256 tiles and friends: nothing to gain
     auto side = [](int win, int want) {               // windows per mosaic side: at most 8, mosaic at most ~1280 px (workspace: 4x tensors)
@@ -586,9 +589,9 @@ Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) {
         return k < want ? k : want;
     };
     m.kx = side(tw, B);
-    if (h->mosaic_kx > 0 && h->mosaic_kx < m.kx) m.kx = h->mosaic_kx;      // S2SR_MOSAIC_KX (diagnostic): narrower mosaics
+    if (mosaic_kx > 0 && mosaic_kx < m.kx) m.kx = mosaic_kx;      // S2SR_MOSAIC_KX (diagnostic): narrower mosaics
     m.ky = side(th, (B + m.kx - 1) / m.kx);
-    if (h->mosaic_kx > 0) { const int want = 16 / m.kx; if (want > m.ky && want <= 8 && want * m.kx <= B) m.ky = want; }
+    if (mosaic_kx > 0) { const int want = 16 / m.kx; if (want > m.ky && want <= 8 && want * m.kx <= B) m.ky = want; }
     if (m.kx * m.ky < 2) return Mosaic();
     // does it pay?  patch area per window with and without
     const double a0 = (double)roundup32(th) * roundup32(tw);
@@ -1153,6 +1156,13 @@ static void plan_chunk_sizes(int units, int u_max, long unit_windows, int per, l
     for (int left = units - best_last - best_mid; left > 0;) { const int u = left < u_max ? left : u_max; sizes.push_back(u); left -= u; }
     if (best_mid) sizes.push_back(best_mid);
     sizes.push_back(best_last);
+}
+
+int s2sr_debug_pick_mosaic(int32_t B, int32_t th, int32_t tw, int32_t* kx, int32_t* ky) {
+    if (!kx || !ky || B < 0 || th <= 0 || tw <= 0) return S2SR_E_INVALID;
+    const Mosaic m = pick_mosaic_cfg(true, 0, B, th, tw);
+    *kx = m.on() ? m.kx : 1; *ky = m.on() ? m.ky : 1;
+    return S2SR_OK;
 }
 
 int s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, int32_t per, int32_t pimg, int32_t ncu, int32_t* sizes,

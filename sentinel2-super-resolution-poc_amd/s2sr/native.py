@@ -109,6 +109,7 @@ _PROTOS = {
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
+    "s2sr_debug_pick_mosaic": (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 2),
     "s2sr_debug_plan_chunks": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_debug_get_config": (C.c_int, [C.c_void_p, C.POINTER(DebugConfig)]),
     "s2sr_debug_conv_trunk": (C.c_int, [C.c_void_p, C.POINTER(DebugTrunkArgs)]),
@@ -198,6 +199,15 @@ def plan_tiles(H: int, W: int, tile: int = 256, pad: int = 10, scale: int = 4) -
     if rc:
         raise S2srError(f"s2sr_plan_tiles: {_ERR.get(rc, rc)}")
     return list(arr)
+
+
+def pick_mosaic(B: int, th: int, tw: int) -> tuple:
+    """(kx, ky): windows per launch image the engine would use for B windows of th x tw (host arithmetic)."""
+    kx, ky = C.c_int32(0), C.c_int32(0)
+    rc = load_library().s2sr_debug_pick_mosaic(B, th, tw, C.byref(kx), C.byref(ky))
+    if rc:
+        raise S2srError(f"s2sr_debug_pick_mosaic failed ({_ERR.get(rc, rc)})")
+    return int(kx.value), int(ky.value)
 
 
 def plan_chunks(units: int, u_max: int, unit_windows: int, per: int, pimg: int, ncu: int = 256) -> List[int]:

@@ -176,3 +176,28 @@ def test_enhance_chunk_plan_properties():
         # front pieces are as large as the workspace allows: at most one of them is not full
         front = sz[:-2] if len(sz) > 2 else []
         assert sum(1 for u in front if u != u_max) <= 1
+
+
+def test_window_mosaic_choice():
+    """pick_mosaic (engine.hip) through s2sr_debug_pick_mosaic: the reference's default 276-pixel windows (tile 256 + 2 x pad 10,
+    cnn_super_resolution.py:244-257) travel 4 x 4 per launch image (1107 -> 1120 of patch extent: 280 x 280 per window instead of
+    288 x 288); windows that are multiples of the 32-pixel patch, single windows and sizes where the separators eat the gain
+    (532-pixel windows: 2 x 2 gives 1065 -> 1088 = 544 per window, the same) stay one per image; a mosaic is never wider than 8
+    windows or ~1280 pixels, and never holds more windows than there are."""
+    from s2sr import native
+    assert native.pick_mosaic(256, 276, 276) == (4, 4)
+    assert native.pick_mosaic(16, 276, 276) == (4, 4)
+    assert native.pick_mosaic(3, 276, 276) == (3, 1)
+    assert native.pick_mosaic(1, 276, 276) == (1, 1)
+    assert native.pick_mosaic(64, 256, 256) == (1, 1)
+    assert native.pick_mosaic(64, 532, 532) == (1, 1)
+    rng = np.random.default_rng(6)
+    for _ in range(300):
+        B, th, tw = int(rng.integers(1, 400)), int(rng.integers(1, 700)), int(rng.integers(1, 700))
+        kx, ky = native.pick_mosaic(B, th, tw)
+        assert 1 <= kx <= 8 and 1 <= ky <= 8
+        if kx * ky > 1:
+            assert kx <= B and kx * (ky - 1) < B                       # no empty rows beyond the last
+            assert kx * (tw + 1) - 1 <= 1280 + tw and ky * (th + 1) - 1 <= 1280 + th
+            r32 = lambda v: (v + 31) // 32 * 32
+            assert r32(ky * (th + 1) - 1) * r32(kx * (tw + 1) - 1) / (kx * ky) <= 0.98 * r32(th) * r32(tw)   # it pays
