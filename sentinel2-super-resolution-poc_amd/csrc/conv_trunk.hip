@@ -214,6 +214,7 @@ struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3
 // FULL: the launch has no ragged edge and no mosaic separators (H % TH == 0, W % 32 == 0, mos_py == 0 -- the 256x256 tile
 // batches): every pixel of every patch is live, so the epilogue carries no px_live arithmetic, no trash-line selects and none
 // of the SGPR spills they cost (conv1-4, 32x32 form: 2544 -> 1880 instructions, 142 -> 6 v_readlane; 71.1 -> 68.8 us per launch).
+// FULL == 3: ragged launches without mosaics (any image that is no multiple of the patch): the extent test alone.
 // FULL == 2: mosaics of the reference's default windows (256 + 2 x 10 = 276 pixels, period 277, at the trunk's scale): the separator
 // test on compile-time constants -- the 8 scalars of the runtime geometry are what pushes the generic form over its SGPR budget.
 template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0>
@@ -615,6 +616,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             const int y = y0 + wave * NP + np;
             ok[np] = FULL == 1 ? true
                    : FULL == 2 ? (y < p.H) && (x < p.W) && (y % 277 < 276) && (x % 277 < 276)
+                   : FULL == 3 ? (y < p.H) && (x < p.W)
                                : px_live(p, pl, y0, x0, y, x);
             opix[np] = (size_t)(y + 1) * p.Wp + (x + 1);
         }
@@ -822,6 +824,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::NW < 64, "vmcnt field is 6 bits");
     if (FULL == 1 && (p.mos_py != 0 || p.H % G::TH != 0 || p.W % 32 != 0)) return hipErrorInvalidValue;
+    if (FULL == 3 && p.mos_py != 0) return hipErrorInvalidValue;
     if (FULL == 2 && (p.mos_py != 277 || p.mos_ry != 276 || p.mos_px != 277 || p.mos_rx != 276)) return hipErrorInvalidValue;
     auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL>;
     static std::mutex attr_mu;
@@ -1541,11 +1544,16 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         // ... and 8x32 patches (2 rows per wave, 7-deep ring) for a single tile: 256 patches for 256 CUs instead of 128 (one 256x256 tile
         // is launch-bound: 351 dependent launches; S2SR_SMALL8=0 keeps the 16x32 form)
         const bool full = !trace && p.mos_py == 0 && p.H % 32 == 0 && p.W % 32 == 0 && !(p.f16_form & 4);   // whole patches only (f16_form bit 2: diagnostic off switch)
+        const bool plain = !trace && p.mos_py == 0 && !(p.f16_form & 4);                                  // ragged, but no mosaic: the extent test alone
         if (n32 < 96 && !trace && !(p.f16_form & 2))
-            return full ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st) : launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
-        if (n32 < 192 && !trace) return full ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st) : launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
+            return full ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st)
+                        : plain ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
+        if (n32 < 192 && !trace)
+            return full ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st)
+                        : plain ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
         if (!trace && (p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
         if (full) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);
+        if (plain && !(p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 3>(p, st);
         if (!trace && !(p.f16_form & 4) && p.mos_py == 277 && p.mos_ry == 276 && p.mos_px == 277 && p.mos_rx == 276)
             return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 2>(p, st);                             // mosaics of 276-pixel windows (tile 256, pad 10)
         return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);

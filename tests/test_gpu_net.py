@@ -660,12 +660,17 @@ def test_whole_patch_conv_forms_change_no_byte(monkeypatch):
     from s2sr.synth import synthetic_tiles
     tiles = synthetic_tiles(12, 256, seed=77)
     small = synthetic_tiles(2, 256, seed=78)[:, :96, :64]
+    # ... and the ragged-without-mosaic forms (extent test only): 32x32, 16x32 and 8x32 patch forms by launch size
+    rag8 = np.ascontiguousarray(synthetic_tiles(8, 256, seed=79)[:, :250, :230])
+    rag4 = np.ascontiguousarray(synthetic_tiles(3, 256, seed=80)[:, :200, :150])
+    rag2 = np.ascontiguousarray(synthetic_tiles(1, 256, seed=81)[:, :100, :70])
     for prec in (native.PREC_F16_HP, native.PREC_F16):
         outs = {}
         for full in ("1", "0"):
-            e = _fresh(monkeypatch, 6, prec, {"S2SR_F16_FULL": full})
+            e = _fresh(monkeypatch, 6, prec, {"S2SR_F16_FULL": full, "S2SR_MOSAIC": "0"})
             assert e.debug_config()["f16_full"] == int(full)
-            outs[full] = (e.forward_batch_u8(tiles), e.forward_batch_u8(tiles[:1]), e.forward_batch_u8(np.ascontiguousarray(small)))
+            outs[full] = (e.forward_batch_u8(tiles), e.forward_batch_u8(tiles[:1]), e.forward_batch_u8(np.ascontiguousarray(small)),
+                          e.forward_batch_u8(rag8), e.forward_batch_u8(rag4), e.forward_batch_u8(rag2))
             e.close()
         for a, b in zip(outs["1"], outs["0"]):
             assert np.array_equal(a, b)
