@@ -20,3 +20,29 @@ for it in range(300):
     else: e.postprocess_u8(np.repeat(np.repeat(img,2,0),2,1), native.pp_wow())
     if it%100==99: print(it, f"free MiB {free():.0f} (start {f0:.0f}) graphs {e.graph_stats()}")
 e.close(); print("after close free", f"{free():.0f}")
+
+# ... and the host side: page-locked outputs (native.pinned_pool) and the staged device-to-host bands must not grow the process
+import gc
+import psutil
+e = native.Engine(num_block=1, precision=native.PREC_F16_HP); e.load_state_dict(synthetic_state_dict(1, seed=0))
+proc = psutil.Process()
+big = rng.integers(0, 256, (1300, 1200, 3), dtype=np.uint8)
+for pinned in (True, False):
+    native.pinned_pool.on = pinned
+    for _ in range(3):
+        e.enhance_u8(big, tile=256, pad=10)
+    gc.collect()
+    r0 = proc.memory_info().rss / 2**20
+    for it in range(30):
+        out = None
+        out = e.enhance_u8(big, tile=256, pad=10)
+        if it % 7 == 0:
+            keep = out[:10].copy()
+    out = None
+    gc.collect()
+    r1 = proc.memory_info().rss / 2**20
+    print(f"pinned outputs {pinned}: host RSS {r0:.0f} -> {r1:.0f} MiB over 30 calls of a 75-MB result; pool hits {native.pinned_pool.hits} misses {native.pinned_pool.misses}")
+    assert r1 - r0 < 200, "host memory grows"
+native.pinned_pool.on = True
+native.pinned_pool.trim()
+e.close()
