@@ -160,6 +160,20 @@ int  s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32
                              int32_t first, int32_t count, void* d_tiles, void* stream);
 int  s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
                                 void* d_out, void* stream);
+/* The same paste for output rows [oy0, oy1) only (d_out is still the whole [4H, 4W, 3] image): a rank that receives the windows
+ * chunk by chunk stitches every band as soon as the window rows that own it have arrived, and copies it out under the next
+ * chunk's compute.  The plan's paste maps stay on the device between calls with the same (H, W, tile, pad). */
+int  s2sr_stitch_rows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                             int32_t oy0, int32_t oy1, void* d_out, void* stream);
+/* s2sr_forward_batch_u8_dev for a PART of a job of `job_windows` (>= B) equal windows: the window mosaic and the workspace are
+ * planned for the whole job, so its parts (the chunks a rank's share of an AOI is cut into) share one workspace and their
+ * hipGraphs.  Same bytes as any other split. */
+int  s2sr_forward_part_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, int32_t th, int32_t tw, int32_t job_windows,
+                              void* d_out, void* stream);
+/* Device -> host: `bytes` from d_src into dst once everything enqueued on `stream` so far has run; returns when they are there.
+ * Replaces the reference's `output.cpu()` (cnn_super_resolution.py:231) for callers that hold device buffers: a destination
+ * from s2sr_host_alloc takes one DMA, a pageable one goes through pinned staging slices. */
+int  s2sr_copy_to_host(s2sr_handle* h, void* dst, const void* d_src, size_t bytes, void* stream);
 
 /* replaces _enhance_for_crops (wow_sr.py:187-209) and enhance_local_contrast /
  * apply_unsharp_mask / enhance_vegetation (farm_sr.py:61-108): HxWx3 u8 RGB -> same. */
@@ -232,13 +246,17 @@ typedef struct s2sr_debug_config {
     int32_t fp8_hp_tail;    /* S2SR_FP8_TAIL=hp */
     int32_t graphs_on;      /* S2SR_GRAPH */
     int32_t trunk_wino;     /* 1: fp16 RDB conv1-4 in the row-Winograd F(2,3) form (S2SR_WINO) */
-    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC); [1]: fp16 conv1-4 loader-wave form (S2SR_F16_LOADER); [2]: conv_last folded 6-stage form (S2SR_LAST_FOLD); [3]: 4-wave tail convs (S2SR_TAIL_W4); [4]: whole-patch fp16 conv1-4 forms allowed (S2SR_F16_FULL) */
+    int32_t reserved[6];    /* [0]: window mosaics on (S2SR_MOSAIC); [1]: fp16 conv1-4 loader-wave form (S2SR_F16_LOADER); [2]: conv_last folded 6-stage form (S2SR_LAST_FOLD); [3]: 4-wave tail convs (S2SR_TAIL_W4); [4]: whole-patch fp16 conv1-4 forms allowed (S2SR_F16_FULL); [5]: workspace allocations since s2sr_create */
 } s2sr_debug_config;
 int  s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out);
 
 /* How `B` equal windows of th x tw travel through the net: kx x ky per launch image with one zero row / column between neighbours
- * (1 x 1: one window per image -- sizes that are multiples of the 32-pixel patch gain nothing).  Host arithmetic only. */
+ * (1 x 1: one window per image -- sizes that are multiples of the 32-pixel patch gain nothing); the windows past the last full
+ * mosaic travel as ONE smaller mosaic.  Chosen for the fewest launched patches.  Host arithmetic only. */
 int  s2sr_debug_pick_mosaic(int32_t B, int32_t th, int32_t tw, int32_t* kx, int32_t* ky);
+/* ... and what that choice LAUNCHES: 32 x 32 patches of floor(B / (kx*ky)) full mosaics plus the remainder's smaller mosaic
+ * (`launched`), next to B plain images (`plain`).  The engine only takes a mosaic when launched <= 0.98 plain.  Host arithmetic only. */
+int  s2sr_debug_mosaic_patches(int32_t B, int32_t th, int32_t tw, int64_t* launched, int64_t* plain);
 /* The chunk plan of a tiled s2sr_enhance_u8 (host arithmetic only, no device needed): `units` row units of `unit_windows` windows
  * each, at most `u_max` units per chunk, `per` windows per launch image (mosaic), `pimg` 32x32 patches per launch image, `ncu`
  * workgroups.  Writes the chunk sizes front to back; *n = their number (cap 0: count only). */

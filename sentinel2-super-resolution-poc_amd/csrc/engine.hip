@@ -140,13 +140,19 @@ struct s2sr_handle {
     int trunk_wino = 0;           // fp16 modes: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip); S2SR_WINO=1: all four, 2: conv2-4 only (Cin >= 96)
     bool trunk_w4 = true;         // RRDB trunk convs on the one-wave-per-SIMD kernel (conv_trunk.hip); S2SR_TRUNK=0: the 8-wave kernel
     bool graphs_on = true;        // S2SR_GRAPH=0 turns it off
-    int mosaic_kx = 0;            // S2SR_MOSAIC_KX (diagnostic)
+    int64_t ws_allocs = 0;        // workspace (re)allocations since s2sr_create (s2sr_debug_get_config reserved[5])
     bool tail_w4 = false;         // S2SR_TAIL_W4=1: split-operand tail convs (up1, up2, hr, last) as 4 waves x twice the rows (one wave per SIMD)
     bool last_fold = true;        // S2SR_LAST_FOLD=0: conv_last (hp) reads all four e4m3 planes (8 stages) instead of folding w_lo into idle couts
     bool f16_full = true;         // S2SR_F16_FULL=0: fp16 conv1-4 never take the whole-patch form (no px_live arithmetic in the epilogue) on 32-multiple launches
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
+    // paste maps of the window plan last stitched through s2sr_stitch_rows_u8_dev (row map, column map), kept on the device:
+    // an AOI is stitched band by band, the maps are uploaded once per (H, W, tile, pad)
+    int32_t* d_stitch_maps = nullptr;
+    size_t stitch_maps_cap = 0;
+    int stitch_key[4] = {0, 0, 0, 0};
+    hipEvent_t host_copy_ev = nullptr;          // s2sr_copy_to_host: orders the copy stream behind the caller's stream
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     int64_t graph_replays = 0, graph_captures = 0;
@@ -274,6 +280,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mo
         }
     }
     HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
+    ++h->ws_allocs;
     HIPCHK(h, hipDeviceSynchronize());
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.D[2] = w.base + oD2; w.U0 = w.base + oU0;
     w.T = w.base + oT; w.Tr[0] = w.base + oT0; w.Tr[1] = w.base + oT1; w.Tr[2] = w.base + oT2; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
@@ -351,6 +358,10 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
     double bytes = px * (up ? 0.25 : 1.0) * cw.cin * 2.0;   // algorithmic: every input element once
     if (epi == EPI_LAST) bytes += px * 3.0 * ((p.out_u8 ? 1.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0));
     else bytes += px * cw.cout * 2.0;
+    // split-operand convs (hp): the e4m3 correction planes they read (4 planes of 32 B per pixel; a folded conv_last reads the
+    // two x_lo planes only) and write (4 planes; 2 when the consumer is a folded conv_last)
+    if (cw.f8) bytes += px * (up ? 0.25 : 1.0) * (cw.fold ? 64.0 : 128.0);
+    if (lo_out) bytes += px * ((p.tail_form & 2) ? 64.0 : 128.0);
     const bool lo8 = h->trunk_w4;                          // one-wave-per-SIMD trunk: lo as e4m3 planes (1 B per channel), else fp16
     if (epi == EPI_RDB5) bytes += px * 64 * (lo8 ? 2.0 : 4.0);          // lo: read + write
     if (epi == EPI_RDB5_RRDB) bytes += px * 64 * (p.xh_skip ? (lo8 ? 5.0 : 8.0) : 12.0);    // lo r/w + RRDB skip: (fp16 hi, lo) pair read (trunk kernel) or fp32 R r/w
@@ -384,7 +395,10 @@ int run_up_subpixel(s2sr_handle* h, hipStream_t st, const ConvW& cw, ConvParams 
     for (int k = 0; k < 2; ++k) {
         p.wpack = cw.d_wphase[k];
         // statistics keep the nominal work of the 3x3 form (2*9*cin*cout per OUTPUT pixel; one row parity = half of them)
-        Scope sc(h, st, F_UP, 2.0 * 9.0 * cw.cin * cw.cout * 2.0 * px, px * (cw.cin * 4.0 + 2.0 * cw.cout * 4.0));
+        // bytes per SOURCE pixel and launch: the source block once (fp16 128 B, + 128 B of e4m3 correction planes in the
+        // split-operand form), two output pixels (both column parities of this row parity) of 128 B (+ 128 B of planes) each
+        // (r03 counted the split-operand figure for the plain fp16 form too: 8.2 TB/s "algorithmic" in the fp8 leg)
+        Scope sc(h, st, F_UP, 2.0 * 9.0 * cw.cin * cw.cout * 2.0 * px, px * (cw.f8 ? 768.0 : 384.0));
         HIPCHK(h, launch_conv_phase(p, k, st, cw.f8));
     }
     return S2SR_OK;
@@ -574,44 +588,78 @@ int group_size(const s2sr_handle* h, int B, int H, int W) {
 // area each, 9 % dead MFMA work) and there are several of them, kx x ky windows share one image with a zero row / column
 // between neighbours (ConvParams::mos_*): 4 x 4 windows of 276 -> 1107 x 1107 -> 1120 x 1120 of patch area, 280 per window.
 // Same bytes out: every output pixel accumulates the same products in the same order wherever its window sits.
-static Mosaic pick_mosaic_cfg(bool mosaic_on, int mosaic_kx, int B, int th, int tw);
-Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) { return pick_mosaic_cfg(h->mosaic_on, h->mosaic_kx, B, th, tw); }
+//
+// B windows travel as floor(B / per) FULL mosaics of kx x ky plus, for the remainder, ONE smaller mosaic of kx' x ky' (ky' =
+// the window rows the remainder needs; a single row is cut to the windows it has).  A sub-mosaic lives inside the planes of the
+// full one: its first row / column past the end is a separator position of the full geometry, which no launch ever stores to.
+// The choice is made on what is LAUNCHED (r03 ADVICE: dividing the mosaic's area by kx * ky assumes every mosaic is full, and a
+// partly filled one costs as much as a full one -- 17 windows of 276 as two 4 x 4 mosaics launched 78 % more patches than 17 plain images).
+static void mosaic_remainder(int rem, int kx, int ky, int* rkx, int* rky) {
+    *rky = (rem + kx - 1) / kx;
+    if (*rky > ky) *rky = ky;
+    *rkx = (*rky == 1) ? rem : kx;
+}
+static long mosaic_area(int th, int tw, int kx, int ky) {   // 32 x 32 patches of one kx x ky mosaic image
+    return (long)(roundup32(ky * (th + 1) - 1) / 32) * (roundup32(kx * (tw + 1) - 1) / 32);
+}
+static long mosaic_patches(int B, int th, int tw, int kx, int ky) {   // patches launched for B windows
+    const int per = kx * ky, full = B / per, rem = B % per;
+    long a = (long)full * mosaic_area(th, tw, kx, ky);
+    if (rem) { int rkx, rky; mosaic_remainder(rem, kx, ky, &rkx, &rky); a += mosaic_area(th, tw, rkx, rky); }
+    return a;
+}
+static Mosaic pick_mosaic_cfg(bool mosaic_on, int B, int th, int tw);
+Mosaic pick_mosaic(const s2sr_handle* h, int B, int th, int tw) { return pick_mosaic_cfg(h->mosaic_on, B, th, tw); }
 // pure host arithmetic (s2sr_debug_pick_mosaic exposes it to the CPU tests)
-static Mosaic pick_mosaic_cfg(bool mosaic_on, int mosaic_kx, int B, int th, int tw) {
+static Mosaic pick_mosaic_cfg(bool mosaic_on, int B, int th, int tw) {
     Mosaic m;
     if (!mosaic_on || B < 2) return m;
-    const double waste = (double)roundup32(th) * roundup32(tw) / ((double)th * tw);
-    if (waste < 1.03) return m;                       // 256 x 256 tiles and friends: nothing to gain
-    auto side = [](int win, int want) {               // windows per mosaic side: at most 8, mosaic at most ~1280 px (workspace: 4x tensors)
+    const long plain = (long)B * (roundup32(th) / 32) * (roundup32(tw) / 32);
+    if ((double)roundup32(th) * roundup32(tw) < 1.03 * (double)th * tw) return m;   // 256 x 256 tiles and friends: nothing to gain
+    auto side = [](int win) {                         // windows per mosaic side: at most 8, mosaic at most ~1280 px (workspace: 4x tensors)
         int k = 1280 / (win + 1);
-        if (k > 8) k = 8;
-        if (k < 1) k = 1;
-        return k < want ? k : want;
+        return k > 8 ? 8 : (k < 1 ? 1 : k);
     };
-    m.kx = side(tw, B);
-    if (mosaic_kx > 0 && mosaic_kx < m.kx) m.kx = mosaic_kx;      // S2SR_MOSAIC_KX (diagnostic): narrower mosaics
-    m.ky = side(th, (B + m.kx - 1) / m.kx);
-    if (mosaic_kx > 0) { const int want = 16 / m.kx; if (want > m.ky && want <= 8 && want * m.kx <= B) m.ky = want; }
-    if (m.kx * m.ky < 2) return Mosaic();
-    // does it pay?  patch area per window with and without
-    const double a0 = (double)roundup32(th) * roundup32(tw);
-    const double a1 = (double)roundup32(m.ky * (th + 1) - 1) * roundup32(m.kx * (tw + 1) - 1) / (m.kx * m.ky);
-    if (a1 > 0.98 * a0) return Mosaic();
-    m.wh = th; m.ww = tw; m.count = B;
+    const int mx = side(tw), my = side(th);
+    // a remainder mosaic is one more sequence of 351 launches on a small image: priced as 64 patches (its launches' floor)
+    auto cost = [&](int kx, int ky) { return mosaic_patches(B, th, tw, kx, ky) + ((B % (kx * ky)) ? 64 : 0); };
+    long lowest = plain;
+    for (int ky = 1; ky <= my; ++ky)
+        for (int kx = 1; kx <= mx; ++kx)
+            if (kx * ky >= 2 && kx * ky <= B && cost(kx, ky) < lowest) lowest = cost(kx, ky);
+    // the LARGEST mosaic within 2 % of the fewest patches (fewer, longer launches: whole rounds of the 256 persistent workgroups
+    // and the launch floors amortise; 256 windows of 276: 3 x 3 launches 1 % fewer patches than 4 x 4 but leaves a remainder in
+    // every chunk of an AOI), then the wider one
+    long best = plain;
+    int bkx = 1, bky = 1;
+    for (int ky = 1; ky <= my; ++ky)
+        for (int kx = 1; kx <= mx; ++kx) {
+            if (kx * ky < 2 || kx * ky > B) continue;
+            const long a = cost(kx, ky);
+            if ((double)a > 1.02 * (double)lowest || a > plain) continue;
+            if (kx * ky > bkx * bky || (kx * ky == bkx * bky && (a < best || (a == best && kx > bkx)))) { best = a; bkx = kx; bky = ky; }
+        }
+    if (bkx * bky >= 2) best = mosaic_patches(B, th, tw, bkx, bky);
+    if (bkx * bky < 2 || (double)best > 0.98 * (double)plain) return Mosaic();
+    m.kx = bkx; m.ky = bky; m.wh = th; m.ww = tw; m.count = B;
     return m;
 }
 
 // [B,th,tw,3] u8 (device) -> u8 [B,4th,4tw,3] and/or f32 [B,3,4th,4tw] (device)
+// `plan`: the mosaic chosen for the whole job this call is a part of (a chunk of an AOI, a group of a batch) -- its geometry
+// sizes the workspace, so every part of the job runs in the same planes (r03 ADVICE: re-picking the mosaic from each chunk's own
+// window count gave a short last chunk another image height, and with it a workspace reallocation, a device synchronise and
+// dropped graphs inside the chunk loop, on every call).  nullptr: choose from B.
 int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const float* d_x_f32, int B, int th, int tw,
-                uint8_t* d_out_u8, float* d_out_f32) {
+                uint8_t* d_out_u8, float* d_out_f32, const Mosaic* plan = nullptr) {
     if (!h->has_weights) return fail(h, S2SR_E_NOWEIGHTS, "s2sr_load_weights has not been called");
     if (B <= 0 || th <= 0 || tw <= 0) return fail(h, S2SR_E_INVALID, "bad batch/tile dims");
     // u8 tiles may travel as window mosaics; "images" below are then mosaics of per = kx*ky windows
-    const Mosaic mo = d_tiles ? pick_mosaic(h, B, th, tw) : Mosaic();
+    const Mosaic mo = !d_tiles ? Mosaic() : (plan ? *plan : pick_mosaic(h, B, th, tw));
     const int per = mo.on() ? mo.kx * mo.ky : 1;
-    const int NI = (B + per - 1) / per;                                       // images to push through the net
-    const int IH = mo.on() ? mo.ky * (th + 1) - 1 : th, IW = mo.on() ? mo.kx * (tw + 1) - 1 : tw;
-    int G = group_size(h, NI, IH, IW);
+    const int IH = mo.on() ? mo.ky * (th + 1) - 1 : th, IW = mo.on() ? mo.kx * (tw + 1) - 1 : tw;   // the plan's image: the workspace geometry
+    const int NIplan = ((plan && plan->count > B ? plan->count : B) + per - 1) / per;
+    int G = group_size(h, NIplan, IH, IW);
     int rc = ensure_workspace(h, G, IH, IW, mo.on() ? th + 1 : 0, mo.on() ? tw + 1 : 0);
     while (rc == S2SR_E_CAPACITY && G > 1) {          // the card is shared: fall back to smaller launch groups rather than fail the job
         G = (G + 1) / 2;
@@ -620,34 +668,49 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
     if (rc) return rc;
     Workspace& w = h->ws;
     const size_t opx = (size_t)16 * th * tw;
+    // segments of equal image geometry: the full mosaics, then the remainder as one smaller mosaic
+    struct Seg { int t0, nwin, kx, ky; };
+    Seg segs[2];
+    int nseg = 0;
+    if (!mo.on()) segs[nseg++] = Seg{0, B, 1, 1};
+    else {
+        const int full = B / per, rem = B % per;
+        if (full) segs[nseg++] = Seg{0, full * per, mo.kx, mo.ky};
+        if (rem) { Seg r{full * per, rem, 1, 1}; mosaic_remainder(rem, mo.kx, mo.ky, &r.kx, &r.ky); segs[nseg++] = r; }
+    }
+    for (int si = 0; si < nseg; ++si) {
+    const Seg& sg = segs[si];
+    const int sper = sg.kx * sg.ky;
+    const int NI = (sg.nwin + sper - 1) / sper;                                // images of this segment
+    const int SH = mo.on() ? sg.ky * (th + 1) - 1 : th, SW = mo.on() ? sg.kx * (tw + 1) - 1 : tw;
     for (int g0 = 0; g0 < NI; g0 += G) {
         const int n = (NI - g0 < G) ? (NI - g0) : G;
-        const int t0 = g0 * per;                                              // first window / tile of this group
-        const int nt = (B - t0 < n * per) ? (B - t0) : n * per;               // windows / tiles in it
+        const int t0 = sg.t0 + g0 * sper;                                     // first window / tile of this group
+        const int nt = (sg.t0 + sg.nwin - t0 < n * sper) ? (sg.t0 + sg.nwin - t0) : n * sper;   // windows / tiles in it
         const uint8_t* in8 = d_tiles ? d_tiles + (size_t)t0 * th * tw * 3 : nullptr;
         const float* in32 = d_tiles ? nullptr : d_x_f32 + (size_t)t0 * 3 * th * tw;
         float* o32 = d_out_f32 ? d_out_f32 + (size_t)t0 * 3 * opx : nullptr;
         uint8_t* o8 = d_out_u8 ? d_out_u8 + (size_t)t0 * 3 * opx : nullptr;
         Mosaic mg = mo;
-        mg.count = nt;
+        mg.kx = sg.kx; mg.ky = sg.ky; mg.count = nt;
         auto enqueue = [&]() -> int {
             {
                 Scope sc(h, st, F_PACK, 0.0, (double)nt * th * tw * (3.0 + 8.0));
-                if (in8 && mo.on()) HIPCHK(h, launch_pack_u8_mosaic(in8, nt, th, tw, mo.kx, mo.ky, w.P0, w.Hp, w.Wp, st));
+                if (in8 && mo.on()) HIPCHK(h, launch_pack_u8_mosaic(in8, nt, th, tw, sg.kx, sg.ky, w.P0, w.Hp, w.Wp, st));
                 else if (in8) HIPCHK(h, launch_pack_u8(in8, n, th, tw, w.P0, w.Hp, w.Wp, st));
                 else HIPCHK(h, launch_pack_f32_nchw(in32, n, 3, th, tw, 255.0f, w.P0, 1, w.Hp, w.Wp, st));
             }
-            return run_net(h, st, n, IH, IW, o32, o8, mo.on() ? mg : Mosaic());
+            return run_net(h, st, n, SH, SW, o32, o8, mo.on() ? mg : Mosaic());
         };
         // the legacy null stream cannot be captured; profiling wants its events between launches
         GraphEntry* ge = nullptr;
         if (h->graphs_on && h->prof <= 0 && st != nullptr) {
             for (GraphEntry& g : h->graphs)
                 if (g.n == n && g.th == th && g.tw == tw && g.in_u8 == in8 && g.in_f32 == in32 && g.out_u8 == o8 &&
-                    g.out_f32 == o32 && g.st == st && g.mos_kx == (mo.on() ? mo.kx : 0) && g.mos_ky == (mo.on() ? mo.ky : 0) &&
+                    g.out_f32 == o32 && g.st == st && g.mos_kx == (mo.on() ? sg.kx : 0) && g.mos_ky == (mo.on() ? sg.ky : 0) &&
                     g.mos_count == (mo.on() ? nt : 0)) { ge = &g; break; }
             if (!ge) {   // first sighting: remember it, launch directly (also warms the per-kernel attributes)
-                if (h->graphs.size() >= 16) {
+                if (h->graphs.size() >= 24) {
                     size_t victim = 0;
                     for (size_t i = 1; i < h->graphs.size(); ++i)
                         if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
@@ -656,7 +719,7 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
                 }
                 GraphEntry g;
                 g.n = n; g.th = th; g.tw = tw; g.in_u8 = in8; g.in_f32 = in32; g.out_u8 = o8; g.out_f32 = o32; g.st = st;
-                g.mos_kx = mo.on() ? mo.kx : 0; g.mos_ky = mo.on() ? mo.ky : 0; g.mos_count = mo.on() ? nt : 0;
+                g.mos_kx = mo.on() ? sg.kx : 0; g.mos_ky = mo.on() ? sg.ky : 0; g.mos_count = mo.on() ? nt : 0;
                 g.last_use = ++h->graph_clock;
                 h->graphs.push_back(g);
                 ge = nullptr;
@@ -690,6 +753,7 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
             rc = enqueue();
             if (rc) return rc;
         }
+    }
     }
     return S2SR_OK;
 }
@@ -747,7 +811,6 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_MOSAIC")) h->mosaic_on = atoi(g) != 0;
-    if (const char* g = getenv("S2SR_MOSAIC_KX")) h->mosaic_kx = atoi(g);
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_F16_FULL")) h->f16_full = atoi(g) != 0;
@@ -797,6 +860,8 @@ void s2sr_destroy(s2sr_handle* h) {
         if (h->stage_buf[i]) hipHostFree(h->stage_buf[i]);
         if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
     }
+    if (h->d_stitch_maps) hipFree(h->d_stitch_maps);
+    if (h->host_copy_ev) hipEventDestroy(h->host_copy_ev);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -987,6 +1052,17 @@ int s2sr_forward_batch_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, in
     return forward_dev(h, st, (const uint8_t*)d_tiles, nullptr, B, th, tw, (uint8_t*)d_out, nullptr);
 }
 
+// A PART of a larger job of `job_windows` equal windows (a chunk of an AOI's windows on one rank, s2sr/dist.py): the window
+// mosaic and the workspace are planned for the whole job, so every part runs in the same planes and replays its graphs.
+int s2sr_forward_part_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t B, int32_t th, int32_t tw, int32_t job_windows, void* d_out,
+                             void* stream) {
+    if (!h || !d_tiles || !d_out || job_windows < B) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const Mosaic mo = pick_mosaic(h, job_windows, th, tw);
+    return forward_dev(h, (hipStream_t)stream, (const uint8_t*)d_tiles, nullptr, B, th, tw, (uint8_t*)d_out, nullptr, mo.on() ? &mo : nullptr);
+}
+
 // Device -> caller's host buffer, `bytes` from `src`, ordered behind everything already on the copy stream; returns when the
 // bytes are in `dst`.  The caller's buffer is ordinary pageable memory (a numpy array): handed to hipMemcpyAsync directly, the
 // runtime moves it with copy KERNELS through its own staging at ~6 GB/s, and those kernels take CUs from the persistent conv
@@ -1067,7 +1143,10 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
     // Groups are enqueued one by one with an event after each; the device-to-host copy of group g
     // runs on the copy stream while group g+1 computes, so only the last group's copy is exposed.
-    const int G = group_size(h, B, th, tw);
+    // one mosaic plan for the whole batch (ragged tiles): every group runs in the same workspace geometry
+    const Mosaic mo = pick_mosaic(h, B, th, tw);
+    const int per = mo.on() ? mo.kx * mo.ky : 1;
+    const int G = (mo.on() ? group_size(h, (B + per - 1) / per, mo.ky * (th + 1) - 1, mo.kx * (tw + 1) - 1) : group_size(h, B, th, tw)) * per;
     const size_t tin = (size_t)th * tw * 3, tout = tin * 16;
     const int ngroups = (B + G - 1) / G;
     while ((int)h->group_done.size() < ngroups) {
@@ -1078,7 +1157,7 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     for (int g = 0; g < ngroups; ++g) {
         const int g0 = g * G, n = (B - g0 < G) ? (B - g0) : G;
         rc = forward_dev(h, h->stream, (const uint8_t*)h->d_scratch[0] + g0 * tin, nullptr, n, th, tw,
-                         (uint8_t*)h->d_scratch[1] + g0 * tout, nullptr);
+                         (uint8_t*)h->d_scratch[1] + g0 * tout, nullptr, mo.on() ? &mo : nullptr);
         if (rc) return rc;
         HIPCHK(h, hipEventRecord(h->group_done[g], h->stream));
     }
@@ -1160,8 +1239,16 @@ static void plan_chunk_sizes(int units, int u_max, long unit_windows, int per, l
 
 int s2sr_debug_pick_mosaic(int32_t B, int32_t th, int32_t tw, int32_t* kx, int32_t* ky) {
     if (!kx || !ky || B < 0 || th <= 0 || tw <= 0) return S2SR_E_INVALID;
-    const Mosaic m = pick_mosaic_cfg(true, 0, B, th, tw);
+    const Mosaic m = pick_mosaic_cfg(true, B, th, tw);
     *kx = m.on() ? m.kx : 1; *ky = m.on() ? m.ky : 1;
+    return S2SR_OK;
+}
+
+int s2sr_debug_mosaic_patches(int32_t B, int32_t th, int32_t tw, int64_t* launched, int64_t* plain) {
+    if (!launched || !plain || B <= 0 || th <= 0 || tw <= 0) return S2SR_E_INVALID;
+    const Mosaic m = pick_mosaic_cfg(true, B, th, tw);
+    *plain = (int64_t)B * (roundup32(th) / 32) * (roundup32(tw) / 32);
+    *launched = m.on() ? (int64_t)mosaic_patches(B, th, tw, m.kx, m.ky) : *plain;
     return S2SR_OK;
 }
 
@@ -1271,8 +1358,8 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         // tail (last, middle) is searched over small sizes for the fewest rounds + exposed copy; the rest goes in front in
         // workspace-sized pieces.  4096 x 4096 at 256/10: 16 rows of 16 windows -> 10 + 5 + 1.
         std::vector<int> chunk_r0;   // first window row of each chunk, plus ny at the end
+        const Mosaic mo = pick_mosaic(h, T, wh, ww);   // ONE plan for the job: every chunk runs in its workspace geometry
         {
-            const Mosaic mo = pick_mosaic(h, T, wh, ww);
             const int per = mo.on() ? mo.kx * mo.ky : 1;
             const int gw = (mo.on() ? group_size(h, (T + per - 1) / per, mo.ky * (wh + 1) - 1, mo.kx * (ww + 1) - 1)
                                     : group_size(h, T, wh, ww)) * per;                  // windows per launch group
@@ -1304,7 +1391,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
                 const int r0 = chunk_r0[c], r1 = chunk_r0[c + 1] < ny ? chunk_r0[c + 1] : ny;
                 const int t0 = r0 * nx, n = (r1 - r0) * nx;
                 rc = forward_dev(h, st, (const uint8_t*)h->d_scratch[2] + t0 * win_in, nullptr, n, wh, ww,
-                                 (uint8_t*)h->d_scratch[4] + t0 * win_out, nullptr);
+                                 (uint8_t*)h->d_scratch[4] + t0 * win_out, nullptr, mo.on() ? &mo : nullptr);
                 if (rc) return rc;
                 int ye = OH;
                 if (r1 < ny)
@@ -1380,9 +1467,10 @@ int s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32_
     return S2SR_OK;
 }
 
-int s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
-                               void* d_out, void* stream) {
-    if (!h || !d_tiles || !d_out || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
+int s2sr_stitch_rows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad, int32_t oy0, int32_t oy1,
+                            void* d_out, void* stream) {
+    if (!h || !d_tiles || !d_out || H <= 0 || W <= 0 || tile <= 0 || pad < 0 || oy0 < 0 || oy1 > 4 * H || oy0 > oy1) return S2SR_E_INVALID;
+    if (oy0 == oy1) return S2SR_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = (hipStream_t)stream;   // NULL = the default stream, as everywhere in HIP
@@ -1392,17 +1480,48 @@ int s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, i
     s2sr_plan_tiles(H, W, tile, pad, 4, wins.data(), T, &T);
     const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
     const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;
-    std::vector<int32_t> rm, cm;
-    build_stitch_maps(wins, nx, ny, 4 * H, 4 * W, rm, cm);
-    int rc = ensure_scratch(h, 3, (rm.size() + cm.size()) * 4);
-    if (rc) return rc;
-    int32_t* d_rm = (int32_t*)h->d_scratch[3];
-    int32_t* d_cm = d_rm + rm.size();
-    HIPCHK(h, hipMemcpyAsync(d_rm, rm.data(), rm.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(d_cm, cm.data(), cm.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, launch_stitch_u8((const uint8_t*)d_tiles, nx, wh * 4, ww * 4, d_rm, d_cm, 4 * H, 4 * W, (uint8_t*)d_out, st));
+    const size_t nrm = 2 * (size_t)(4 * H), ncm = 2 * (size_t)(4 * W);
+    if (h->stitch_key[0] != H || h->stitch_key[1] != W || h->stitch_key[2] != tile || h->stitch_key[3] != pad + 1) {
+        std::vector<int32_t> rm, cm;
+        build_stitch_maps(wins, nx, ny, 4 * H, 4 * W, rm, cm);
+        if (h->stitch_maps_cap < (nrm + ncm) * 4) {
+            HIPCHK(h, hipDeviceSynchronize());     // a stitch of the previous plan may still read the old maps
+            if (h->d_stitch_maps) HIPCHK(h, hipFree(h->d_stitch_maps));
+            h->d_stitch_maps = nullptr; h->stitch_maps_cap = 0; h->stitch_key[0] = 0;
+            HIPCHK(h, hipMalloc((void**)&h->d_stitch_maps, (nrm + ncm) * 4));
+            h->stitch_maps_cap = (nrm + ncm) * 4;
+        } else {
+            HIPCHK(h, hipDeviceSynchronize());
+        }
+        HIPCHK(h, hipMemcpy(h->d_stitch_maps, rm.data(), nrm * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_stitch_maps + nrm, cm.data(), ncm * 4, hipMemcpyHostToDevice));
+        h->stitch_key[0] = H; h->stitch_key[1] = W; h->stitch_key[2] = tile; h->stitch_key[3] = pad + 1;
+    }
+    const int32_t* d_rm = h->d_stitch_maps;
+    const int32_t* d_cm = d_rm + nrm;
+    HIPCHK(h, launch_stitch_u8((const uint8_t*)d_tiles, nx, wh * 4, ww * 4, d_rm + 2 * (size_t)oy0, d_cm, oy1 - oy0, 4 * W,
+                               (uint8_t*)d_out + (size_t)oy0 * 4 * W * 3, st));
     return S2SR_OK;
+}
+
+int s2sr_stitch_windows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                               void* d_out, void* stream) {
+    return s2sr_stitch_rows_u8_dev(h, d_tiles, H, W, tile, pad, 0, 4 * H, d_out, stream);
+}
+
+// Device -> host for callers that hold device buffers (s2sr/dist.py's consuming rank): `bytes` from d_src into dst once
+// everything enqueued on `stream` so far is done; returns when the bytes are in dst.  A destination from s2sr_host_alloc is
+// filled by one DMA, a pageable one through the pinned staging slices (d2h_staged) -- never the runtime's copy kernels, which
+// take CUs from the conv workgroups of whatever computes meanwhile.
+int s2sr_copy_to_host(s2sr_handle* h, void* dst, const void* d_src, size_t bytes, void* stream) {
+    if (!h || !dst || !d_src) return S2SR_E_INVALID;
+    if (bytes == 0) return S2SR_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (!h->host_copy_ev) HIPCHK(h, hipEventCreateWithFlags(&h->host_copy_ev, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->host_copy_ev, (hipStream_t)stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->host_copy_ev, 0));
+    return d2h_staged(h, (uint8_t*)dst, (const uint8_t*)d_src, bytes, false);
 }
 
 int s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
@@ -1695,7 +1814,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     memset(out, 0, sizeof *out);
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
-    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0; out->reserved[4] = h->f16_full ? 1 : 0;
+    out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0; out->reserved[4] = h->f16_full ? 1 : 0; out->reserved[5] = (int32_t)h->ws_allocs;
     return S2SR_OK;
 }
 

@@ -5,12 +5,19 @@ The path shards by independent units: every window of
 `RealESRGAN._tile_process` (reference cnn_super_resolution.py:247-257) and every tile of a batch
 is an independent forward.  Collectives used, and only these:
   * broadcast of the flat weight blob from rank 0, once per model load;
-  * all-gather of the ranks' u8 output tiles (equal-sized chunks, tail padded), after which
-    every rank pastes with the reference's crop + overwrite rule -- or, with `dst=`, a gather to the
-    one rank that consumes the mosaic.
-The compute backend is an object with four methods (`device`, `cut`, `forward`, `stitch`);
-`NativeBackend` is the product one (libs2sr.so on an MI355X, no fallback).  Tests drive the
-same orchestration over gloo with a numpy stand-in backend.
+  * gather (to the one rank that consumes the mosaic) or all-gather of the ranks' u8 output windows.
+
+The AOI path (`enhance_distributed`) is chunked like the single-GPU one (engine.hip enhance_impl): a rank's
+contiguous block of windows is cut into chunks (whole launch groups of window mosaics, shrinking towards the end:
+`native.plan_chunks`), all chunks are enqueued on the compute stream up front, and chunk k's outputs travel on a
+communication stream while chunk k+1 computes -- into views of ONE preallocated buffer on the consumer, at the
+windows' plan indices (no list of parts, no concatenation).  The consumer stitches every band of output rows as
+soon as the window rows that own it have arrived and lands it in a page-locked host array (`native.pinned_pool`)
+through `s2sr_copy_to_host`, so gather, stitch and device-to-host copy of everything but the last chunk hide under
+compute.
+
+The compute backend is an object with the interface of `BackendBase`; `NativeBackend` is the product one
+(libs2sr.so on an MI355X, no fallback).  Tests drive the same orchestration over gloo with a numpy stand-in.
 """
 from __future__ import annotations
 
@@ -58,15 +65,72 @@ def load_broadcast_weights(engine: "native.Engine", state_dict, num_block: int, 
         engine.load_blob(blob.numpy())
 
 
-class NativeBackend:
+class BackendBase:
+    """What the orchestration needs from a compute backend.  A backend implements `device`, `cut`, `forward`,
+    `stitch` (and `postprocess`); the rest have defaults in terms of those, which the CPU stand-in of the tests uses
+    and `NativeBackend` replaces with calls that neither allocate nor copy more than they must."""
+    device = torch.device("cpu")
+
+    # -- streams (no-ops on the CPU) ---------------------------------------------------------
+    def comm_stream(self):
+        return None
+
+    def record(self, stream=None):
+        """An event on `stream` (None: the compute stream) -- or None on the CPU."""
+        return None
+
+    def wait(self, stream, event) -> None:
+        pass
+
+    def on(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+    # -- compute -----------------------------------------------------------------------------
+    def forward_into(self, tiles: torch.Tensor, out: torch.Tensor, job_windows: int) -> None:
+        out.copy_(self.forward(tiles))
+
+    def chunk_plan(self, per: int, wh: int, ww: int) -> List[int]:
+        """Chunk sizes (windows, front to back) for a rank's block of `per` windows of wh x ww."""
+        return [per] if per else []
+
+    def stitch_rows(self, tiles: torch.Tensor, H: int, W: int, tile: int, pad: int, y0: int, y1: int, img: torch.Tensor, stream=None) -> None:
+        img[y0:y1] = self.stitch(tiles, H, W, tile, pad)[y0:y1]
+
+    # -- host side ---------------------------------------------------------------------------
+    def alloc_host(self, shape) -> np.ndarray:
+        return np.empty(shape, np.uint8)
+
+    def to_host(self, dst: np.ndarray, src: torch.Tensor, stream=None) -> None:
+        dst[...] = src.cpu().numpy()
+
+
+class NativeBackend(BackendBase):
     """libs2sr.so on `cuda:<index>`; tensors are torch CUDA tensors, calls run on the current stream."""
 
     def __init__(self, engine: native.Engine, device_index: int):
         self.engine = engine
         self.device = torch.device("cuda", device_index)
+        self._comm = None
 
-    def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+    def _stream(self, stream=None) -> int:
+        return (stream or torch.cuda.current_stream(self.device)).cuda_stream
+
+    def comm_stream(self):
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        return self._comm
+
+    def record(self, stream=None):
+        ev = torch.cuda.Event()
+        ev.record(stream or torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait(self, stream, event) -> None:
+        (stream or torch.cuda.current_stream(self.device)).wait_event(event)
+
+    def on(self, stream):
+        return torch.cuda.stream(stream)
 
     def cut(self, img: torch.Tensor, tile: int, pad: int, first: int, count: int, slots: int,
             wh: int, ww: int) -> torch.Tensor:
@@ -82,10 +146,37 @@ class NativeBackend:
         self.engine.forward_batch_u8_dev(tiles.data_ptr(), B, h, w, out.data_ptr(), self._stream())
         return out
 
+    def forward_into(self, tiles: torch.Tensor, out: torch.Tensor, job_windows: int) -> None:
+        B, h, w, _ = tiles.shape
+        assert tiles.is_contiguous() and out.is_contiguous() and out.shape == (B, 4 * h, 4 * w, 3)
+        self.engine.forward_part_u8_dev(tiles.data_ptr(), B, h, w, max(job_windows, B), out.data_ptr(), self._stream())
+
+    def chunk_plan(self, per: int, wh: int, ww: int) -> List[int]:
+        """The single-GPU path's planner (engine.hip plan_chunk_sizes) on this rank's block: units of one launch image (a
+        window mosaic), at most one launch group per chunk, small chunks last (their gather / stitch / copy is exposed)."""
+        if per <= 0:
+            return []
+        kx, ky = native.pick_mosaic(per, wh, ww)
+        unit = kx * ky
+        units = -(-per // unit)
+        r32 = lambda v: (v + 31) // 32
+        pimg = r32(ky * (wh + 1) - 1) * r32(kx * (ww + 1) - 1) if unit > 1 else r32(wh) * r32(ww)
+        group = self.engine.group_images()
+        sizes, left = [], per
+        for u in native.plan_chunks(units, group, unit, unit, pimg, 256):
+            n = min(u * unit, left)
+            if n > 0:
+                sizes.append(n)
+            left -= n
+        return sizes
+
     def stitch(self, tiles: torch.Tensor, H: int, W: int, tile: int, pad: int) -> torch.Tensor:
         out = torch.empty((4 * H, 4 * W, 3), dtype=torch.uint8, device=self.device)
         self.engine.stitch_windows_u8_dev(tiles.data_ptr(), H, W, tile, pad, out.data_ptr(), self._stream())
         return out
+
+    def stitch_rows(self, tiles, H, W, tile, pad, y0, y1, img, stream=None) -> None:
+        self.engine.stitch_rows_u8_dev(tiles.data_ptr(), H, W, tile, pad, y0, y1, img.data_ptr(), self._stream(stream))
 
     def postprocess(self, img: torch.Tensor, prm) -> torch.Tensor:
         """[H,W,3] u8 RGB on the device -> same (CLAHE + unsharp + vegetation, wow_sr.py:187-209)."""
@@ -94,8 +185,47 @@ class NativeBackend:
         self.engine.postprocess_batch_u8_dev(img.data_ptr(), 1, H, W, prm, out.data_ptr(), self._stream())
         return out
 
+    def alloc_host(self, shape) -> np.ndarray:
+        return native.pinned_pool.empty(shape, np.uint8)       # page-locked: every band lands with one DMA
 
-def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10, dst=0, enhance_crops=None):
+    def to_host(self, dst: np.ndarray, src: torch.Tensor, stream=None) -> None:
+        assert src.is_contiguous()
+        self.engine.copy_to_host(dst, src.data_ptr(), self._stream(stream))
+
+
+def _collect(src: torch.Tensor, parts, dst) -> None:
+    """gather (dst = a rank) or all-gather (dst None) of `src` into the views `parts`.  RCCL moves device tensors as they are;
+    gloo (CPU tests, and the two-ranks-on-one-GPU rehearsal of bench.py) gets host copies of device tensors."""
+    staged = src.is_cuda and dist.get_backend() != "nccl"
+    s = src.cpu() if staged else src
+    p = parts
+    if staged and parts is not None:
+        p = [torch.empty(tuple(t.shape), dtype=t.dtype) for t in parts]
+    if dst is None:
+        dist.all_gather(p, s)
+    else:
+        dist.gather(s, p, dst=dst)
+    if staged and parts is not None:
+        for t, c in zip(parts, p):
+            if t is not src:
+                t.copy_(c)
+
+
+def _row_bands(wins, nx: int, ny: int, OH: int) -> List[Tuple[int, int]]:
+    """Output rows each window ROW of the plan owns under the reference's overwrite order (:278: later windows win):
+    band[y] = [y0, y1) of the rows whose last covering window row is y (empty for a duplicate row that a later one covers)."""
+    owner = np.full(OH, -1, np.int64)
+    for y in range(ny):
+        w = wins[y * nx]
+        owner[w.oy1:w.oy2] = y
+    bands = []
+    for y in range(ny):
+        idx = np.nonzero(owner == y)[0]
+        bands.append((int(idx[0]), int(idx[-1]) + 1) if idx.size else (0, 0))
+    return bands
+
+
+def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10, dst=0, enhance_crops=None, stats: dict = None):
     """`RealESRGAN.enhance` (cnn_super_resolution.py:217-280) with the windows of the tiled branch
     sharded over the process group.  Every rank passes the same image.
 
@@ -106,39 +236,102 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
     enhance_crops: post-process parameters (native.pp_wow() / pp_farm()) or None.  The mosaic is BGR like
     everything `enhance` handles (wow_sr.py:85,94); the post-process runs on its RGB view, on the
     consuming rank(s), over the WHOLE mosaic after the stitch -- CLAHE's 8x8 grid is image-global
-    (wow_sr.py:191-192), so it cannot run per window."""
+    (wow_sr.py:191-192), so it cannot run per window.
+    stats: optional dict that receives the chunk plan and band count of this call."""
     world, rank = dist.get_world_size(), dist.get_rank()
     H, W, _ = img.shape
     dev = backend.device
     x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(dev)
+    consumer = dst is None or rank == dst
 
-    def finish(mosaic: torch.Tensor) -> np.ndarray:
+    def finish_whole(mosaic: torch.Tensor) -> np.ndarray:
         if enhance_crops is not None:
             rgb = mosaic.flip(2).contiguous()
             mosaic = backend.postprocess(rgb, enhance_crops).flip(2).contiguous()
-        return mosaic.cpu().numpy()
+        out = backend.alloc_host(tuple(mosaic.shape))
+        backend.to_host(out, mosaic.contiguous())
+        return out
 
     if H * W <= tile * tile * 4:
         # whole-image branch: a single unit, nothing to shard; the consuming rank(s) compute it
-        if dst is not None and rank != dst:
+        if not consumer:
             return None
-        return finish(backend.forward(x.unsqueeze(0))[0])
+        return finish_whole(backend.forward(x.unsqueeze(0))[0])
+
     wins = native.plan_tiles(H, W, tile, pad, 4)
     T = len(wins)
+    nx, ny = -(-W // tile), -(-H // tile)
     wh, ww = wins[0].y2 - wins[0].y1, wins[0].x2 - wins[0].x1
     first, count, per = shard_range(T, world, rank)
+    chunks = backend.chunk_plan(per, wh, ww)            # the same plan on every rank: the gathers are symmetric
+    assert sum(chunks) == per and all(c > 0 for c in chunks), (chunks, per)
+    if stats is not None:
+        stats.update(windows=T, per_rank=per, chunks=list(chunks))
+    oshape = (4 * wh, 4 * ww, 3)
     mine = backend.cut(x, tile, pad, first, count, per, wh, ww)          # [per, wh, ww, 3], tail slots zero
-    out = backend.forward(mine).contiguous()                             # [per, 4wh, 4ww, 3]
-    if dst is None:
-        gathered = torch.empty((world * per,) + tuple(out.shape[1:]), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, out)
-    else:
-        parts = [torch.empty_like(out) for _ in range(world)] if rank == dst else None
-        dist.gather(out, parts, dst=dst)
-        if rank != dst:
-            return None
-        gathered = torch.cat(parts, 0)
-    return finish(backend.stitch(gathered[:T].contiguous(), H, W, tile, pad))
+    # ONE buffer for every window of the plan on a consumer, at the windows' plan indices (tail slots of the last ranks
+    # past T are padding); this rank computes straight into its own block of it.  Other ranks: a buffer of their block.
+    allbuf = torch.empty((world * per,) + oshape, dtype=torch.uint8, device=dev) if consumer else None
+    own = allbuf[rank * per:(rank + 1) * per] if consumer else torch.empty((per,) + oshape, dtype=torch.uint8, device=dev)
+
+    # every chunk's compute goes onto the compute stream now; an event per chunk releases its transfer
+    offs, done = [], []
+    o = 0
+    for c in chunks:
+        offs.append(o)
+        backend.forward_into(mine[o:o + c], own[o:o + c], per)
+        done.append(backend.record())
+        o += c
+
+    comm = backend.comm_stream()
+    image = torch.empty((4 * H, 4 * W, 3), dtype=torch.uint8, device=dev) if consumer else None
+    bands = _row_bands(wins, nx, ny, 4 * H) if consumer else None
+    direct = consumer and enhance_crops is None          # bands go to the host as they complete
+    out = backend.alloc_host((4 * H, 4 * W, 3)) if direct else None
+    arrived = np.zeros(world * per, bool)
+    row_done = np.zeros(ny, bool)
+    nbands = 0
+    for k, c in enumerate(chunks):
+        backend.wait(comm, done[k])
+        with backend.on(comm):
+            src = own[offs[k]:offs[k] + c]
+            if world > 1 or dist.get_backend() == "nccl":       # (one rank over RCCL still goes through the collective)
+                # receive straight into the plan slots of the one buffer; this rank's own slot IS `src` (computed in place)
+                parts = None
+                if consumer:
+                    parts = [allbuf[r * per + offs[k]:r * per + offs[k] + c] for r in range(world)]
+                    parts[rank] = src
+                _collect(src, parts, dst)
+            if not consumer:
+                continue
+            for r in range(world):
+                arrived[r * per + offs[k]:r * per + offs[k] + c] = True
+            # bands whose window rows are complete: stitch on the communication stream (behind the transfer), then to the host
+            for y in range(ny):
+                if row_done[y] or not arrived[y * nx:(y + 1) * nx].all():
+                    continue
+                row_done[y] = True
+                y0, y1 = bands[y]
+                if y1 <= y0:
+                    continue
+                backend.stitch_rows(allbuf, H, W, tile, pad, y0, y1, image, comm)
+                if direct:
+                    backend.to_host(out[y0:y1], image[y0:y1], comm)
+                nbands += 1
+    if stats is not None:
+        stats["bands"] = nbands
+    if not consumer:
+        if comm is not None:
+            comm.synchronize()
+        return None
+    assert row_done.all()
+    if direct:
+        if comm is not None:
+            comm.synchronize()
+        return out
+    if comm is not None:
+        backend.wait(None, backend.record(comm))          # the post-process runs on the compute stream, behind the last stitch
+    return finish_whole(image)
 
 
 def forward_batch_distributed(backend, tiles: np.ndarray) -> np.ndarray:
@@ -153,4 +346,6 @@ def forward_batch_distributed(backend, tiles: np.ndarray) -> np.ndarray:
     out = backend.forward(mine)
     gathered = torch.empty((world * per,) + tuple(out.shape[1:]), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, out.contiguous())
-    return gathered[:B].cpu().numpy()
+    res = backend.alloc_host((B,) + tuple(out.shape[1:]))
+    backend.to_host(res, gathered[:B])
+    return res

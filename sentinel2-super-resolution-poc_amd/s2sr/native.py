@@ -90,6 +90,9 @@ _PROTOS = {
     "s2sr_tile_process_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_cut_windows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
     "s2sr_stitch_windows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
+    "s2sr_stitch_rows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
+    "s2sr_forward_part_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p]),
+    "s2sr_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "s2sr_postprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
     "s2sr_postprocess_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(PPParams), C.c_void_p, C.c_void_p]),
@@ -110,6 +113,7 @@ _PROTOS = {
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
     "s2sr_debug_pick_mosaic": (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 2),
+    "s2sr_debug_mosaic_patches": (C.c_int, [C.c_int32] * 3 + [C.POINTER(C.c_int64)] * 2),
     "s2sr_debug_plan_chunks": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_debug_get_config": (C.c_int, [C.c_void_p, C.POINTER(DebugConfig)]),
     "s2sr_debug_conv_trunk": (C.c_int, [C.c_void_p, C.POINTER(DebugTrunkArgs)]),
@@ -210,6 +214,15 @@ def pick_mosaic(B: int, th: int, tw: int) -> tuple:
     return int(kx.value), int(ky.value)
 
 
+def mosaic_patches(B: int, th: int, tw: int) -> tuple:
+    """(launched, plain): 32x32 patches the engine launches for B windows of th x tw, and what B plain images would cost."""
+    a, b = C.c_int64(0), C.c_int64(0)
+    rc = load_library().s2sr_debug_mosaic_patches(B, th, tw, C.byref(a), C.byref(b))
+    if rc:
+        raise S2srError(f"s2sr_debug_mosaic_patches failed ({_ERR.get(rc, rc)})")
+    return int(a.value), int(b.value)
+
+
 def plan_chunks(units: int, u_max: int, unit_windows: int, per: int, pimg: int, ncu: int = 256) -> List[int]:
     """Chunk sizes (row units, front to back) s2sr_enhance_u8 would use; host arithmetic, works without a GPU."""
     lib = load_library()
@@ -294,11 +307,16 @@ class Engine:
         self._lib = load_library()
         self._h = C.c_void_p()
         self.num_block = num_block
+        self.precision, self.group = precision, group
         cfg = _Config(num_block, 64, 32, 4, precision, device, group, 0)
         rc = self._lib.s2sr_create(C.byref(cfg), C.byref(self._h))
         if rc:
             msg = self._lib.s2sr_last_error(None)
             raise S2srError(f"s2sr_create failed ({_ERR.get(rc, rc)}): {msg.decode() if msg else ''}")
+
+    def group_images(self) -> int:
+        """Images per launch group (engine.hip group_size: 16, 32 for the fp8 trunk, or what the constructor was given)."""
+        return self.group if self.group > 0 else (32 if self.precision == PREC_FP8 else 16)
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc: int, what: str):
@@ -395,6 +413,21 @@ class Engine:
         self._check(self._lib.s2sr_stitch_windows_u8_dev(self._h, d_tiles, H, W, tile, pad, d_out, C.c_void_p(stream)),
                     "s2sr_stitch_windows_u8_dev")
 
+    def stitch_rows_u8_dev(self, d_tiles: int, H: int, W: int, tile: int, pad: int, oy0: int, oy1: int, d_out: int, stream: int = 0):
+        """Output rows [oy0, oy1) of the paste; d_out is the whole [4H,4W,3] image."""
+        self._check(self._lib.s2sr_stitch_rows_u8_dev(self._h, d_tiles, H, W, tile, pad, oy0, oy1, d_out, C.c_void_p(stream)),
+                    "s2sr_stitch_rows_u8_dev")
+
+    def forward_part_u8_dev(self, d_in: int, B: int, h: int, w: int, job_windows: int, d_out: int, stream: int = 0):
+        """B windows that are a part of a job of `job_windows` (one mosaic plan and workspace for the whole job)."""
+        self._check(self._lib.s2sr_forward_part_u8_dev(self._h, d_in, B, h, w, job_windows, d_out, C.c_void_p(stream)),
+                    "s2sr_forward_part_u8_dev")
+
+    def copy_to_host(self, dst: np.ndarray, d_src: int, stream: int = 0):
+        """Device -> the (C-contiguous) host array `dst`, behind everything on `stream`; blocks until the bytes are there."""
+        assert dst.flags["C_CONTIGUOUS"]
+        self._check(self._lib.s2sr_copy_to_host(self._h, _ptr(dst), C.c_void_p(d_src), dst.nbytes, C.c_void_p(stream)), "s2sr_copy_to_host")
+
     # -- post-process -----------------------------------------------------------------------
     def postprocess_u8(self, rgb: np.ndarray, prm: PPParams) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
@@ -488,6 +521,7 @@ def _debug_config(self) -> dict:
     d["last_fold"] = int(c.reserved[2])
     d["tail_w4"] = int(c.reserved[3])
     d["f16_full"] = int(c.reserved[4])
+    d["ws_allocs"] = int(c.reserved[5])
     return d
 
 

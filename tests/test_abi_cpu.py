@@ -179,11 +179,13 @@ def test_enhance_chunk_plan_properties():
 
 
 def test_window_mosaic_choice():
-    """pick_mosaic (engine.hip) through s2sr_debug_pick_mosaic: the reference's default 276-pixel windows (tile 256 + 2 x pad 10,
-    cnn_super_resolution.py:244-257) travel 4 x 4 per launch image (1107 -> 1120 of patch extent: 280 x 280 per window instead of
-    288 x 288); windows that are multiples of the 32-pixel patch, single windows and sizes where the separators eat the gain
-    (532-pixel windows: 2 x 2 gives 1065 -> 1088 = 544 per window, the same) stay one per image; a mosaic is never wider than 8
-    windows or ~1280 pixels, and never holds more windows than there are."""
+    """pick_mosaic (engine.hip) through s2sr_debug_pick_mosaic / s2sr_debug_mosaic_patches: the reference's default 276-pixel
+    windows (tile 256 + 2 x pad 10, cnn_super_resolution.py:244-257) travel 4 x 4 per launch image (1107 -> 1120 of patch extent:
+    280 x 280 per window instead of 288 x 288); windows that are multiples of the 32-pixel patch, single windows and sizes where
+    the separators eat the gain (532-pixel windows) stay one per image; a mosaic is never wider than 8 windows or ~1280 pixels and
+    never holds more windows than there are.  The choice is made on what is LAUNCHED -- full mosaics plus one smaller mosaic for
+    the remainder (r03 ADVICE: 17 windows as two 4 x 4 mosaics launched 2450 patches against 1377 for plain images): for every
+    B the launched patches are at most the plain ones."""
     from s2sr import native
     assert native.pick_mosaic(256, 276, 276) == (4, 4)
     assert native.pick_mosaic(16, 276, 276) == (4, 4)
@@ -191,13 +193,34 @@ def test_window_mosaic_choice():
     assert native.pick_mosaic(1, 276, 276) == (1, 1)
     assert native.pick_mosaic(64, 256, 256) == (1, 1)
     assert native.pick_mosaic(64, 532, 532) == (1, 1)
+    r32 = lambda v: (v + 31) // 32
+    for B in range(1, 65):                    # the ADVICE's examples: 5, 9, 17, 20, 25 windows of 276
+        launched, plain = native.mosaic_patches(B, 276, 276)
+        assert plain == B * 81 and launched <= plain, (B, launched, plain)
+        kx, ky = native.pick_mosaic(B, 276, 276)
+        if kx * ky > 1:
+            assert launched <= 0.98 * plain, (B, kx, ky, launched, plain)
+        if B % 16 == 0:
+            assert (kx, ky) == (4, 4), (B, kx, ky)
+        # the launched figure is full mosaics + one remainder mosaic of ceil(rem / kx) rows (one row: cut to its windows)
+        per = kx * ky
+        full, rem = divmod(B, per)
+        exp = full * r32(ky * 277 - 1) * r32(kx * 277 - 1)
+        if rem and per > 1:
+            rky = min(-(-rem // kx), ky)
+            rkx = rem if rky == 1 else kx
+            exp += r32(rky * 277 - 1) * r32(rkx * 277 - 1)
+        assert launched == (exp if per > 1 else plain), (B, kx, ky, launched, exp)
+    assert native.mosaic_patches(17, 276, 276) == (1225 + 81, 17 * 81)
+    assert native.mosaic_patches(25, 276, 276)[0] <= 1225 + 3 * 35 * 9 + 1     # 16 + 9: one 4 x 4 and a 4 x 3 (9 of its 12 slots used)
     rng = np.random.default_rng(6)
     for _ in range(300):
         B, th, tw = int(rng.integers(1, 400)), int(rng.integers(1, 700)), int(rng.integers(1, 700))
         kx, ky = native.pick_mosaic(B, th, tw)
+        launched, plain = native.mosaic_patches(B, th, tw)
+        assert launched <= plain
         assert 1 <= kx <= 8 and 1 <= ky <= 8
         if kx * ky > 1:
-            assert kx <= B and kx * (ky - 1) < B                       # no empty rows beyond the last
+            assert kx * ky <= B
             assert kx * (tw + 1) - 1 <= 1280 + tw and ky * (th + 1) - 1 <= 1280 + th
-            r32 = lambda v: (v + 31) // 32 * 32
-            assert r32(ky * (th + 1) - 1) * r32(kx * (tw + 1) - 1) / (kx * ky) <= 0.98 * r32(th) * r32(tw)   # it pays
+            assert launched <= 0.98 * plain                           # it pays

@@ -19,36 +19,60 @@ REPO = Path(__file__).resolve().parent.parent
 PKG = REPO / "sentinel2-super-resolution-poc_amd"
 
 
-class FakeBackend:
-    """CPU stand-in with the NativeBackend interface; the model is nearest-x4 of (3*v+7) mod 256."""
-    device = torch.device("cpu")
+def make_fake_backend():
+    """CPU stand-in with the NativeBackend interface (s2sr.dist.BackendBase supplies the chunk / band / host defaults);
+    the model is nearest-x4 of (3*v+7) mod 256.  Its chunk plan cuts a rank's block into pieces of 1, 2, 3, ... windows so
+    that the chunked gathers, the band-wise stitch and the host copies all run with several chunks per rank."""
+    from s2sr import dist as sd
+    from s2sr import native
 
-    def cut(self, img, tile, pad, first, count, slots, wh, ww):
-        from s2sr import native
-        H, W, _ = img.shape
-        wins = native.plan_tiles(H, W, tile, pad, 4)
-        out = torch.zeros((slots, wh, ww, 3), dtype=torch.uint8)
-        for i in range(count):
-            w = wins[first + i]
-            out[i] = img[w.y1:w.y2, w.x1:w.x2]
-        return out
+    class FakeBackend(sd.BackendBase):
+        device = torch.device("cpu")
+        calls = {"stitch_rows": 0, "to_host": 0}
 
-    def forward(self, tiles):
-        t = ((tiles.to(torch.int32) * 3 + 7) % 256).to(torch.uint8)
-        return t.repeat_interleave(4, 1).repeat_interleave(4, 2)
+        def cut(self, img, tile, pad, first, count, slots, wh, ww):
+            H, W, _ = img.shape
+            wins = native.plan_tiles(H, W, tile, pad, 4)
+            out = torch.zeros((slots, wh, ww, 3), dtype=torch.uint8)
+            for i in range(count):
+                w = wins[first + i]
+                out[i] = img[w.y1:w.y2, w.x1:w.x2]
+            return out
 
-    def postprocess(self, img, prm):
-        return 255 - img                 # stand-in for the image-global post-process
+        def forward(self, tiles):
+            t = ((tiles.to(torch.int32) * 3 + 7) % 256).to(torch.uint8)
+            return t.repeat_interleave(4, 1).repeat_interleave(4, 2)
 
-    def stitch(self, tiles, H, W, tile, pad):
-        from s2sr import native
-        wins = native.plan_tiles(H, W, tile, pad, 4)
-        out = torch.zeros((4 * H, 4 * W, 3), dtype=torch.uint8)
-        for i, w in enumerate(wins):     # sequential paste == the reference's loop (:247-278)
-            t = tiles[i]
-            th, tw = t.shape[0], t.shape[1]
-            out[w.oy1:w.oy2, w.ox1:w.ox2] = t[w.crop_top:th - w.crop_bottom, w.crop_left:tw - w.crop_right]
-        return out
+        def chunk_plan(self, per, wh, ww):
+            sizes, n = [], 1
+            while sum(sizes) < per:
+                sizes.append(min(n, per - sum(sizes)))
+                n += 1
+            return sizes
+
+        def postprocess(self, img, prm):
+            return 255 - img                 # stand-in for the image-global post-process
+
+        def stitch(self, tiles, H, W, tile, pad):
+            wins = native.plan_tiles(H, W, tile, pad, 4)
+            out = torch.zeros((4 * H, 4 * W, 3), dtype=torch.uint8)
+            for i, w in enumerate(wins):     # sequential paste == the reference's loop (:247-278)
+                t = tiles[i]
+                th, tw = t.shape[0], t.shape[1]
+                out[w.oy1:w.oy2, w.ox1:w.ox2] = t[w.crop_top:th - w.crop_bottom, w.crop_left:tw - w.crop_right]
+            return out
+
+        def stitch_rows(self, tiles, H, W, tile, pad, y0, y1, img, stream=None):
+            self.calls["stitch_rows"] += 1
+            # poison the windows that have not arrived?  They are whatever torch.empty left: the band must not depend on them,
+            # which the byte comparison with the sequential paste checks.
+            super().stitch_rows(tiles, H, W, tile, pad, y0, y1, img, stream)
+
+        def to_host(self, dst, src, stream=None):
+            self.calls["to_host"] += 1
+            super().to_host(dst, src, stream)
+
+    return FakeBackend()
 
 
 def _free_port():
@@ -67,7 +91,7 @@ def _worker(rank, world, port, cases, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from s2sr import dist as sd
     from s2sr.weights import synthetic_state_dict, flatten_state_dict
-    be = FakeBackend()
+    be = make_fake_backend()
     res = []
     for (H, W, tile, pad, seed) in cases:
         img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
@@ -79,8 +103,14 @@ def _worker(rank, world, port, cases, q):
     img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
     g = sd.enhance_distributed(be, img, tile, pad, dst=world - 1, enhance_crops=object())
     assert (g is None) == (rank != world - 1)
-    g0 = sd.enhance_distributed(be, img, tile, pad)                  # the default: gather to rank 0, the job's one consumer
+    st = {}
+    n_rows = be.calls["stitch_rows"]
+    g0 = sd.enhance_distributed(be, img, tile, pad, stats=st)        # the default: gather to rank 0, the job's one consumer
     assert (g0 is None) == (rank != 0)
+    # several chunks per rank, and (on the consumer) the image went out band by band, one band per distinct window row
+    assert len(st["chunks"]) >= 2 and sum(st["chunks"]) == st["per_rank"], st
+    if rank == 0:
+        assert st["bands"] >= 2 and be.calls["stitch_rows"] - n_rows == st["bands"], (st, be.calls)
     if rank == 0:
         assert np.array_equal(g0, res[0])
     if rank == world - 1:

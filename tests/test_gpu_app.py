@@ -289,7 +289,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, S2SR_BENCH_SAME_DEVICE="1", S2SR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, S2SR_BENCH_SAME_DEVICE="1", S2SR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", S2SR_BENCH_AOI="1024")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(repo / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"],
                        capture_output=True, text=True, env=env, timeout=600, cwd=str(repo))
@@ -300,3 +300,7 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "RCCL all-gather" in d["config"]["workload"] and "cpu_baseline" not in d
     assert d["roofline"]["timed_pass"]["graph_replays"] >= 1
+    # the strong-scaling AOI leg (configs[2]): one 1024x1024 image over the two ranks, 16 windows in blocks of 8, host image on rank 0
+    ao = d["aoi_strong_scaling"]
+    assert ao["n_gpus"] == 2 and ao["scaling"] == "strong" and ao["value"] > 0 and ao["rccl_ranks_seen"] == 2
+    assert "blocks of 8 per rank" in ao["workload"]
