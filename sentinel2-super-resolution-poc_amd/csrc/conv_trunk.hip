@@ -61,6 +61,10 @@
 #ifndef S2SR_F16_LOENC
 #define S2SR_F16_LOENC 1   // conv_trunk_f16 conv5: the short form of the lo encoding (v_fma_mix_f32 + v_cvt_scalef32_pk_fp8_f32), see the epilogue
 #endif
+#ifndef S2SR_F16_EARLYBIAS
+#define S2SR_F16_EARLYBIAS 1    // conv_trunk_f16: 1 = the bias is requested (inline-asm loads) before the ring fill and consumed behind the first
+                                // wait; 0 = plain C++ loads in front of the first DMA instruction, as until r03 (two dependent round trips)
+#endif
 #ifndef S2SR_F16_PULL
 #define S2SR_F16_PULL 0         // conv_trunk_f16 conv5: 1 = the DMA quota of a patch's first stage is issued inside the previous patch's epilogue
                                 // (the slot is free by then), so the ring does not run down while the wave converts and stores.  Measured
@@ -112,7 +116,8 @@ struct TG {
     static constexpr int PV = PW + PFW;                        // vector-memory instructions per wave and stage
     static constexpr int NW = PV * (R - 2);                    // ... that may stay in flight at a barrier
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
-    static_assert(3 * CT <= NP + 2, "one A fragment per step must cover a kernel column");
+    static constexpr int AK = (3 * CT + NP + 1) / (NP + 2);    // A fragments fetched per step: the 3 * CT of the next kernel column must fit the NP + 2 steps of this one
+    static_assert(3 * CT <= AK * (NP + 2), "the A fragments of a kernel column must fit its steps");
     static_assert(PW <= T - 3, "DMA slots must fit in front of the barrier step");
     static_assert(S2SR_L2PF <= R - 1 || S2SR_L2PF == 0 || true, "");
 };
@@ -202,6 +207,17 @@ __device__ __forceinline__ void wait_release_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+__device__ __forceinline__ f32x4 asm_load16v(const char* addr) {   // as asm_load16, destination in architectural VGPRs
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t asm_load4v(const char* addr) {
+    uint32_t r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
 template <int EPI, int CT, int NP>
 struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3x3.hip EpiStores)
     static constexpr int value = (EPI == EPI_LRELU) ? CT * 2 * NP : CT * 3 * NP;     // conv5: two fp16 blocks of x + one e4m3 plane of lo per 32 couts
@@ -238,14 +254,23 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;
     if (my_tiles <= 0) return;                                   // workgroup-uniform
     const int NS = p.nstage;
-    if (TRACE && p.trace && !(p.dbg & 20) && tid == 0) {         // whole-kernel clock stamps (tools/trunk_anatomy.py)
+    // dbg bit 5 (32): launch anatomy of a small launch (tools/launch_anatomy.py), wave 0 lane 0: [0] entry (s_memrealtime), [1] entry,
+    // [2] prologue DMA issued, [3] first barrier passed (stage 0 landed), [4] last stage of the last patch done, [5] its epilogue's
+    // stores issued, [6] exit after vmcnt(0) (all s_memtime), [7] exit (s_memrealtime)
+    const bool kAnat = TRACE && p.trace && (p.dbg & 32) && tid == 0;
+    if (kAnat) {
+        p.trace[(size_t)blockIdx.x * 24 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.trace[(size_t)blockIdx.x * 24 + 1] = __builtin_amdgcn_s_memtime();
+    }
+    if (TRACE && p.trace && !(p.dbg & 52) && tid == 0) {         // whole-kernel clock stamps (tools/trunk_anatomy.py)
         p.trace[(size_t)blockIdx.x * 24 + 20] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 22] = __builtin_amdgcn_s_memtime();
     }
     const uint32_t sblk = (uint32_t)p.sHp * p.sWp * 32;
     const size_t oblk = (size_t)p.Hp * p.Wp * 32;
 
-    if (tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
+    constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
+    constexpr bool kAccV = (EPI == EPI_LRELU) && S2SR_F16_ACCV && !TRACE;
 
     // ---- per-lane global offsets of this wave's PW DMA pieces (patch independent)
     uint32_t loff[G::PW];
@@ -360,6 +385,26 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         return;
     }
 
+    // The bias is REQUESTED here and consumed behind the first wait of the ring (r04 launch anatomy: as plain C++ the two
+    // dependent round trips -- bias to LDS, bias to the C operand -- sat in front of the first DMA instruction: 1.5 of the
+    // 2 us prologue of a 7-8 us single-tile launch).  Inline asm: the compiler's own wait would drain the ring.
+    // BEHIND the loader wave's branch: a hidden load whose destination is dead on some path lands in registers the compiler has
+    // handed to something else there (the loader's DMA offsets: a memory fault, r04).
+    constexpr bool kEarly = S2SR_F16_EARLYBIAS != 0;
+    uint32_t bias_l = 0;
+    if (!kEarly && tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
+    if (kEarly && !kBiasC) bias_l = asm_load4v((const char*)(p.bias + (tid < CT * 32 ? tid : 0)));
+    f32x4 bq[kBiasC ? CT : 1][4];
+    if (kEarly && kBiasC) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const char* a = (const char*)(p.bias + ct * 32 + 8 * g + 4 * hh);
+                bq[kBiasC ? ct : 0][g] = kAccV ? asm_load16v(a) : asm_load16(a);
+            }
+    }
+
     // ---- fragment addresses inside a slot: per-lane base + immediate
     uint32_t bbase[3];
 #pragma unroll
@@ -377,11 +422,9 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     f32x16 acc[CT][NP];
     // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
     // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
-    constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
-    constexpr bool kAccV = (EPI == EPI_LRELU) && S2SR_F16_ACCV && !TRACE;
-    constexpr bool kPull = kTrunk && (S2SR_F16_PULL != 0) && G::PFW == 0;
+    constexpr bool kPull = false;
     f32x16 bacc[kBiasC ? CT : 1];
-    if (kBiasC) {
+    if (!kEarly && kBiasC) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -402,6 +445,10 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #pragma unroll
         for (int r = 0; r < R - 1; ++r) pf_next();                // the stages the DMA below fetches itself
     }
+    // (r04, measured and dropped -- tools/ab_latency.sh, profiles/r04_latency_anatomy.txt: issuing exactly as many stage loads
+    // as a workgroup runs stages, instead of letting the cursor park on the last stage and re-load it R-1 times, with waits that
+    // count the loads really younger: one tile 4.00 -> 4.20 ms, 64x64 2.83 -> 3.10 ms, the 32-tile step 82.2 -> 83.7 ms.  The
+    // redundant loads cost nothing measurable; the run-time wait selection and its scalar state do.)
 #pragma unroll
     for (int r = 0; r < (PROD ? 0 : R - 1); ++r) {
         cursor_next();
@@ -419,8 +466,30 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         for (int r = R - 1; r < S2SR_L2PF; ++r) pf_next();        // (only when the prefetch runs further ahead than R-1 prologue rounds)
     }
     uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
-    if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the loader waited for the data
-    else wait_release_barrier<G::NW>();                           // stage 0 has landed (and the bias is visible)
+    if (kAnat) p.trace[(size_t)blockIdx.x * 24 + 2] = __builtin_amdgcn_s_memtime();
+    if (PROD) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the loader waited for the data (vmcnt: my bias request)
+    else wait_release_barrier<G::NW>();                           // stage 0 has landed
+    if (kAnat) p.trace[(size_t)blockIdx.x * 24 + 3] = __builtin_amdgcn_s_memtime();
+    // the bias requests are older than every DMA instruction: they have landed too.  conv5 reads it from LDS in its epilogue
+    // (every stage barrier lies in between), conv1-4 feed it to the first MFMA of each accumulator as C.
+    if (kEarly && !kBiasC) {
+        asm volatile("" : "+v"(bias_l));
+        if (tid < CT * 32) ((uint32_t*)(smem + G::BIAS_OFF))[tid] = bias_l;
+    }
+    if (kEarly && kBiasC) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (kAccV) asm_land_v(bq[kBiasC ? ct : 0][g]);
+                else asm_land(bq[kBiasC ? ct : 0][g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bacc[kBiasC ? ct : 0][4 * g + i] = bq[kBiasC ? ct : 0][g][i];
+            }
+            if (kAccV) asm volatile("" : "+v"(bacc[kBiasC ? ct : 0]));
+            else asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+        }
+    }
     {
         const char* sb = smem;
 #pragma unroll
@@ -482,7 +551,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const char* sn = smem + next_off;
         // conv5 (kPull): the first stage of every patch but the first finds its DMA quota already issued by the epilogue before it
         const bool pulled = kPull && FIRST && !first_patch;
-        if (!pulled && !PROD) cursor_next();                      // the stage R-1 ahead: its DMA rides on this stage
+        if (!PROD) cursor_next();                                 // the stage R-1 ahead: its DMA rides on this stage
         if (G::PFW > 0) pf_next();                                // and S2SR_L2PF stages beyond it: L2 prefetch
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
@@ -512,9 +581,15 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 else breg[u % 6] = *(const f16x8*)(sn + bbase[0] + (u - G::T) * G::ROWB);
             }
             // A fragments: the next kernel column's, one per step; behind the barrier the next stage's column 0
-            if (dx < 2 && s < 3 * CT) {
-                const int f = s, dy = f / CT, ct = f % CT;
-                acol[dx + 1][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3 + dx + 1) * CT + ct) * 1024);
+            if (dx < 2) {
+#pragma unroll
+                for (int k = 0; k < G::AK; ++k) {             // AK = 1 in every form but the 8x32-patch conv5 (6 fragments, 4 steps)
+                    const int f = s * G::AK + k;
+                    if (f < 3 * CT) {
+                        const int dy = f / CT, ct = f % CT;
+                        acol[dx + 1][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3 + dx + 1) * CT + ct) * 1024);
+                    }
+                }
             }
             if (t >= G::T - 3) {
                 const int dy = t - (G::T - 3);
@@ -529,7 +604,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
-                if ((sl * (G::T - 3)) / G::PW == t && !pulled && !PROD) dma_piece(sl, dma_off);
+                if ((sl * (G::T - 3)) / G::PW == t && !PROD) dma_piece(sl, dma_off);
 #pragma unroll
             for (int k = 0; k < G::PFW; ++k)
                 if (((2 * k + 1) * (G::T - 3)) / (2 * G::PFW) == t) pf_piece(k);
@@ -808,11 +883,17 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             stage(integral_constant<bool, true>{}, integral_constant<int, -1>{}, first_patch);
             for (int st = 1; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
         }
+        if (kAnat && it == my_tiles - 1) p.trace[(size_t)blockIdx.x * 24 + 4] = __builtin_amdgcn_s_memtime();
         epilogue(it);
+        if (kAnat && it == my_tiles - 1) p.trace[(size_t)blockIdx.x * 24 + 5] = __builtin_amdgcn_s_memtime();
     }
     // nothing may still be on its way into this workgroup's LDS when it ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (TRACE && p.trace && !(p.dbg & 20) && tid == 0) {
+    if (kAnat) {
+        p.trace[(size_t)blockIdx.x * 24 + 6] = __builtin_amdgcn_s_memtime();
+        p.trace[(size_t)blockIdx.x * 24 + 7] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (TRACE && p.trace && !(p.dbg & 52) && tid == 0) {
         p.trace[(size_t)blockIdx.x * 24 + 21] = __builtin_amdgcn_s_memrealtime();
         p.trace[(size_t)blockIdx.x * 24 + 23] = __builtin_amdgcn_s_memtime();
     }
@@ -1545,6 +1626,7 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         // is launch-bound: 351 dependent launches; S2SR_SMALL8=0 keeps the 16x32 form)
         const bool full = !trace && p.mos_py == 0 && p.H % 32 == 0 && p.W % 32 == 0 && !(p.f16_form & 4);   // whole patches only (f16_form bit 2: diagnostic off switch)
         const bool plain = !trace && p.mos_py == 0 && !(p.f16_form & 4);                                  // ragged, but no mosaic: the extent test alone
+        if (n32 < 96 && trace) return launch_trunk_t<1, 2, 7, EPI_LRELU, true>(p, st);               // launch anatomy of the single-tile form
         if (n32 < 96 && !trace && !(p.f16_form & 2))
             return full ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st)
                         : plain ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
@@ -1558,8 +1640,19 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
             return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 2>(p, st);                             // mosaics of 276-pixel windows (tile 256, pad 10)
         return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
     }
-    if (ct == 2 && epi == EPI_RDB5) return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);
-    if (ct == 2 && epi == EPI_RDB5_RRDB) return launch_trunk_t<2, 4, 4, EPI_RDB5_RRDB, false>(p, st);
+    // conv5: 16x32 patches (4 rows per wave, 4-deep ring); single tiles take 8x32 patches (2 rows per wave, 5-deep ring): one
+    // 256x256 tile is 128 patches of 16x32 -- half the CUs idle through twelve MFMA-bound stages (r04 kernel trace: 24 us per
+    // conv5 launch, 69 of them = 37 % of one tile's latency) -- and 256 of 8x32.  Same accumulation order, same bytes.
+    // force_form 1 / 5: name the patch form (per-layer parity hook).
+    if (ct == 2 && (epi == EPI_RDB5 || epi == EPI_RDB5_RRDB)) {
+        const long n16 = (long)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.N;
+        const bool small = force_form == 5 || (force_form == 0 && n16 < 192 && !(p.f16_form & 2));
+        if (epi == EPI_RDB5) {
+            if (small) return trace ? launch_trunk_t<2, 2, 5, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 2, 5, EPI_RDB5, false>(p, st);
+            return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);
+        }
+        return small ? launch_trunk_t<2, 2, 5, EPI_RDB5_RRDB, false>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5_RRDB, false>(p, st);
+    }
     return hipErrorNotSupported;
 }
 

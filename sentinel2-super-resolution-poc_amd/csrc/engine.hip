@@ -1931,7 +1931,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
         }
         hipError_t e;
         if (wino) e = launch_conv_trunk_wino(p, st);
-        else e = launch_conv_trunk(p, Cout / 32, epi, st, false, kind == 0 ? a->form : 0);
+        else e = launch_conv_trunk(p, Cout / 32, epi, st, false, a->form);
         if (e != hipSuccess) return fail(h, S2SR_E_HIP, std::string("launch_conv_trunk: ") + hipGetErrorString(e));
     } else {
         p.seg_len = Cin / 32; p.nstage = (p.seg_len + 1) & ~1; p.wscale = (const int32_t*)d_ws.p;

@@ -130,8 +130,11 @@ def test_f16_conv14_whole_patch_forms(eng, form, base):
         eng.debug_conv_trunk(K14, x, w, b, form=form)
 
 
+# conv5 patch forms: 1 = 16x32 patches / 4-deep ring (batches), 5 = 8x32 patches / 5-deep ring (single tiles, r04: one 256x256
+# tile gives 256 patches instead of 128; its A fragments are fetched two per step)
+@pytest.mark.parametrize("form", [1, 5])
 @pytest.mark.parametrize("N,H,W", [(1, 16, 32), (1, 17, 70), (2, 33, 33)])
-def test_f16_conv5_random(eng, N, H, W):
+def test_f16_conv5_random(eng, N, H, W, form):
     """conv5: v = 0.2 * (conv + b) + (x + lo), written as the (fp16 hi, e4m3(lo * 2^lo_exp)) pair; rdb3's conv5 adds
     0.2 * v + skip with the skip read as such a pair."""
     rng = np.random.default_rng(H * 10 + W)
@@ -140,7 +143,7 @@ def test_f16_conv5_random(eng, N, H, W):
     lo = (rng.integers(-7, 8, size=(N, 64, H, W)) * 2.0 ** (-4 - le)).astype(np.float32)       # exact in e4m3 at 2^lo_exp
     conv = _conv64(x, w, b)
     v1 = 0.2 * conv + (x[:, :64].astype(np.float64) + lo)
-    y1 = eng.debug_conv_trunk(K5, x, w, b, lo=lo)
+    y1 = eng.debug_conv_trunk(K5, x, w, b, lo=lo, form=form)
 
     def bound(v):      # accumulation order + the 4-bit lo half: |v - (hi + lo8)| <= 2^-11 |v| * 2^-4, + e4m3 subnormal step 2^-9-le
         return 2e-4 * max(1.0, np.abs(v).max()) + np.abs(v) * 2.0 ** -15 + 2.0 ** (-9 - le)
@@ -151,12 +154,16 @@ def test_f16_conv5_random(eng, N, H, W):
     slo = (rng.integers(-7, 8, size=(N, 64, H, W)) * 2.0 ** (-4 - le)).astype(np.float32)
     skip = (shi.astype(np.float64) + slo).astype(np.float32)
     assert np.array_equal(skip.astype(np.float64), shi.astype(np.float64) + slo)                # exactly representable as a pair
-    y2 = eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip)
+    y2 = eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=form)
+    if form == 5:    # both patch forms accumulate in the same order: the same bytes
+        assert np.array_equal(y1, eng.debug_conv_trunk(K5, x, w, b, lo=lo, form=1))
+        assert np.array_equal(y2, eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=1))
     v2 = 0.2 * v1 + skip.astype(np.float64)
     assert np.all(np.abs(y2 - v2) <= bound(v2)), float(np.abs(y2 - v2).max())
 
 
-def test_f16_conv5_integer_layout(eng):
+@pytest.mark.parametrize("form", [1, 5])
+def test_f16_conv5_integer_layout(eng, form):
     """Single-tap kernels with power-of-two data: 0.2 * acc is rounded once in fp32 (the same for oracle and kernel up to
     the fused form), so compare against the fp32 formula with 1 ulp of slack on the 0.2 product and exact channel maps."""
     rng = np.random.default_rng(11)
@@ -167,7 +174,7 @@ def test_f16_conv5_integer_layout(eng):
         for c in range(64):
             w[c, (c * 11 + 5) % 192, t // 3, t % 3] = 5.0          # 0.2 * 5 * integer: integers up to fp32 rounding of 0.2f
         b = np.zeros(64, np.float32)
-        y = eng.debug_conv_trunk(K5, x, w, b)
+        y = eng.debug_conv_trunk(K5, x, w, b, form=form)
         v = 0.2 * _conv64(x, w, b) + x[:, :64]
         assert np.abs(y - v).max() <= 1e-5, (t, float(np.abs(y - v).max()))
 
