@@ -1053,6 +1053,13 @@ static bool use_w4() {
 template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
     constexpr int R = (CT == 1) ? 5 : 4;
+#if !S2SR_EXPERIMENTAL
+    // the RDB convs run on conv_trunk.hip; their 8-wave / 4-wave forms here (r01's trunk, S2SR_TRUNK=0 / S2SR_W4=1) and the
+    // upsample-on-load up-convs (S2SR_NO_SUBPIXEL) are in the experimental library only
+    if constexpr (!UP && ((CT == 1 && EPI == EPI_LRELU) || (CT == 2 && (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB)))) return hipErrorNotSupported;
+    else if constexpr (UP && EPI != EPI_DEBUG) return hipErrorNotSupported;
+    else return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
+#else
     if constexpr (!UP && ((CT == 1 && EPI == EPI_LRELU) || (CT == 2 && (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB)))) {
         if (use_w4()) {
             if constexpr (CT == 1) {
@@ -1072,21 +1079,27 @@ static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
         if (n32 >= 192) return launch_t<1, EPI_LRELU, false, 8, 4, 3>(p, st);
     }
     return launch_t<CT, EPI, UP, 8, 2, R>(p, st);
+#endif
 }
 
 hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_out, hipStream_t st, bool f8_in) {
     if (f8_in) {   // split-operand mode: fp16 main term + fp8 correction planes in; lo_out: fp8 planes out as well
+#if S2SR_EXPERIMENTAL
         if (p.tail_form & 1) {   // one wave per SIMD: 4 waves x 4 rows, the same 16x32 patch and ring
             if (ct == 2 && lo_out && epi == EPI_LRELU && !up) return launch_t<2, EPI_LRELU, false, 4, 4, 4, false, 1, 1, true>(p, st);
             if (ct == 1 && !lo_out && epi == EPI_LAST && !up && p.nstage == 6 && p.fold_lo) return launch_t<1, EPI_LAST, false, 4, 4, 4, false, 3, 1, true>(p, st);
         }
+#endif
         const bool full = p.mos_py == 0 && p.H % 16 == 0 && p.W % 32 == 0 && !(p.tail_form & 8);   // whole 16x32 patches (bit 3: diagnostic off switch)
         if (ct == 2 && lo_out && epi == EPI_LRELU && !up && (p.tail_form & 2))   // conv_hr in front of a folded conv_last: no hi8 planes out
             return full ? launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true, -1, true>(p, st)
                         : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 2, 1, true>(p, st);
         if (ct == 2 && lo_out && epi == EPI_BODY && !up && full) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true, -1, true>(p, st);
         if (ct == 2 && lo_out) {
-            if (epi == EPI_LRELU) return up ? launch_t<2, EPI_LRELU, true, 8, 2, 4, false, 1, 1, true>(p, st) : launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 1, 1, true>(p, st);
+#if S2SR_EXPERIMENTAL
+            if (epi == EPI_LRELU && up) return launch_t<2, EPI_LRELU, true, 8, 2, 4, false, 1, 1, true>(p, st);
+#endif
+            if (epi == EPI_LRELU && !up) return launch_t<2, EPI_LRELU, false, 8, 2, 4, false, 1, 1, true>(p, st);
             if (epi == EPI_BODY && !up) return launch_t<2, EPI_BODY, false, 8, 2, 4, false, 1, 1, true>(p, st);
         }
         if (ct == 1 && !lo_out && epi == EPI_LAST && !up) {
@@ -1116,10 +1129,12 @@ hipError_t launch_conv(const ConvParams& p, int ct, int epi, bool up, bool lo_ou
 // one ROW parity of a split-operand up-conv in sub-pixel form (both column parities inside the launch;
 // p.H, p.W = source dims, p.Hp, p.Wp = 2x tensor)
 hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f8) {
+#if S2SR_EXPERIMENTAL
     if (f8 && (p.tail_form & 1)) {   // one wave per SIMD: 4 waves x 2 source rows
         if (py == 0) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 0>(p, st);
         if (py == 1) return launch_t<4, EPI_LRELU, false, 4, 2, 4, false, 1, 1, true, 1>(p, st);
     }
+#endif
     if (f8 && p.mos_py == 0 && p.H % 8 == 0 && p.W % 32 == 0 && !(p.tail_form & 8)) {   // whole 8x32 source patches
         if (py == 0) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 0, true>(p, st);
         if (py == 1) return launch_t<4, EPI_LRELU, false, 8, 1, 4, false, 1, 1, true, 1, true>(p, st);
@@ -1134,6 +1149,7 @@ hipError_t launch_conv_phase(const ConvParams& p, int py, hipStream_t st, bool f
     return hipErrorInvalidValue;
 }
 
+#if S2SR_EXPERIMENTAL
 hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
     if (use_w4()) {
         if (ct == 1) return launch_t<1, EPI_LRELU, false, 4, 8, 3, true>(p, st);
@@ -1142,6 +1158,7 @@ hipError_t launch_conv_trace(const ConvParams& p, int ct, hipStream_t st) {
     if (ct == 1) return launch_t<1, EPI_LRELU, false, 8, 4, 3, true>(p, st);
     return launch_t<2, EPI_RDB5, false, 8, 2, 4, true>(p, st);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // host-side weight repack.  Layout: [stage = cin/16][tap][ct][lane 0..63][j 0..7] fp16 with

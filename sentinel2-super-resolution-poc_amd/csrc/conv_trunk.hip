@@ -45,11 +45,6 @@
 
 #include "s2sr_internal.h"
 
-#ifndef S2SR_L2PF
-#define S2SR_L2PF 0        // conv_trunk_f16: stages an L2 prefetch runs ahead of the LDS-DMA cursor.  Measured (tools/ab_macro.sh,
-                           // profiles/r02_trunk_anatomy.txt): 1 -> -5 %, 2 -> -15 % on conv1-4: the LDS-DMA path is throughput-, not
-                           // latency-bound, extra requests cost.  Kept as a switch, off.
-#endif
 #ifndef S2SR_F16_BIASC
 #define S2SR_F16_BIASC 1   // conv_trunk_f16 conv1-4: bias as the first MFMA's C operand + packed LeakyReLU (0: bias add in the epilogue)
 #endif
@@ -64,11 +59,6 @@
 #ifndef S2SR_F16_EARLYBIAS
 #define S2SR_F16_EARLYBIAS 1    // conv_trunk_f16: 1 = the bias is requested (inline-asm loads) before the ring fill and consumed behind the first
                                 // wait; 0 = plain C++ loads in front of the first DMA instruction, as until r03 (two dependent round trips)
-#endif
-#ifndef S2SR_F16_PULL
-#define S2SR_F16_PULL 0         // conv_trunk_f16 conv5: 1 = the DMA quota of a patch's first stage is issued inside the previous patch's epilogue
-                                // (the slot is free by then), so the ring does not run down while the wave converts and stores.  Measured
-                                // (tools/ab_macro.sh, one box, A/B/A/B): conv5 232.8 / 232.1 against 229.9 / 231.2 us -- nothing; off.
 #endif
 #ifndef S2SR_DIAG_NOLO
 #define S2SR_DIAG_NOLO 0        // numerics diagnostic (tools/nolo_probe.sh): the fp16 trunk carried WITHOUT its lo half.  Measured: max-abs
@@ -106,20 +96,14 @@ struct TG {
     static constexpr int STAGE_BYTES = NSTI * 1024;
     static constexpr int RING_BYTES = R * STAGE_BYTES;
     static constexpr int BIAS_OFF = RING_BYTES;
-    static constexpr int PF_OFF = BIAS_OFF + CT * 128;         // 256-B landing pad of the L2 prefetch
-    static constexpr int LDS_BYTES = PF_OFF + 256;
+    static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
     static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per stage
-    // L2 prefetch of a later stage's slab: one 4-byte LDS-DMA lane per 128-B line (9 lines per slab row) into a dummy LDS
-    // word -- no register destination, counted in vmcnt like every other vector-memory operation
-    static constexpr int PFL = S2SR_L2PF > 0 ? SH * 9 : 0;     // lines per slab plane
-    static constexpr int PFW = (PFL + 64 * WAVES - 1) / (64 * WAVES);   // prefetch instructions per wave and stage
-    static constexpr int PV = PW + PFW;                        // vector-memory instructions per wave and stage
+    static constexpr int PV = PW;                              // vector-memory instructions per wave and stage (r02's L2-prefetch lanes, measured -5..-15 %, are gone)
     static constexpr int NW = PV * (R - 2);                    // ... that may stay in flight at a barrier
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static constexpr int AK = (3 * CT + NP + 1) / (NP + 2);    // A fragments fetched per step: the 3 * CT of the next kernel column must fit the NP + 2 steps of this one
     static_assert(3 * CT <= AK * (NP + 2), "the A fragments of a kernel column must fit its steps");
     static_assert(PW <= T - 3, "DMA slots must fit in front of the barrier step");
-    static_assert(S2SR_L2PF <= R - 1 || S2SR_L2PF == 0 || true, "");
 };
 
 // LDS-DMA, 16 B per lane (conv3x3.hip glds16).  FORCE_UNIFORM: the stamped diagnostic build's divergent stamp
@@ -238,7 +222,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     using G = TG<CT, NP, R>;
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert(EPI == EPI_LRELU || kTrunk, "trunk kernel: conv1-4 (LRELU) and conv5 (RDB5 / RDB5_RRDB) only");
-    static_assert(PROD == 0 || (EPI == EPI_LRELU && !TRACE && S2SR_L2PF == 0), "loader wave: conv1-4 form only");
+    static_assert(PROD == 0 || (EPI == EPI_LRELU && !TRACE), "loader wave: conv1-4 form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -310,38 +294,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             else st_i = NS - 1;                                   // clamp: re-load the last stage (into a free slot)
         }
     };
-    // ---- L2 prefetch cursor: S2SR_L2PF stages further ahead than the DMA cursor.  The DMA throughput of a CU is
-    // (bytes in flight) / latency and the bytes in flight are capped by the LDS ring; pulling a stage's lines into L2 early
-    // shortens the latency its LDS-DMA sees later.
-    int it_p = 0, st_p = 0;
-    const char* pbase_p = nullptr;
-    const char* sb_p = nullptr;
-    auto pf_next = [&]() __attribute__((always_inline)) {
-        if (st_p == 0) {
-            const int tile = it_p * nwg + slot_in_round;
-            const int n = tile / tpi;
-            const int trem = tile - n * tpi;
-            const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
-            pbase_p = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
-        }
-        sb_p = pbase_p + (size_t)st_p * sblk;
-        if (++st_p == NS) {
-            if (it_p + 1 < my_tiles) { st_p = 0; ++it_p; }
-            else st_p = NS - 1;
-        }
-    };
-    uint32_t pfoff[G::PFW > 0 ? G::PFW : 1];
-#pragma unroll
-    for (int k = 0; k < G::PFW; ++k) {
-        int l = (wave + k * 4) * 64 + lane;                       // line of the slab plane
-        if (l >= G::PFL) l = G::PFL - 1;
-        pfoff[k] = (uint32_t)((l / 9) * p.sWp * 32 + (l % 9) * 128);
-    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
-    auto pf_piece = [&](int k) __attribute__((always_inline)) {
-        uint32_t m = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)G::PF_OFF);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(pfoff[k]), "s"(sb_p), "s"(m) : "memory");
-    };
     auto dma_piece = [&](int sl, uint32_t slot_off) __attribute__((always_inline)) {
         int j = wave + sl * 4;
         if (j > G::NSTI - 1) j = G::NSTI - 1;
@@ -422,7 +375,6 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     f32x16 acc[CT][NP];
     // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
     // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
-    constexpr bool kPull = false;
     f32x16 bacc[kBiasC ? CT : 1];
     if (!kEarly && kBiasC) {
 #pragma unroll
@@ -440,11 +392,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
     f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
 
-    // ---- prologue: R-1 stages in flight (+ the L2 prefetch of the stages behind them), then the first fragments of stage 0
-    if (G::PFW > 0) {
-#pragma unroll
-        for (int r = 0; r < R - 1; ++r) pf_next();                // the stages the DMA below fetches itself
-    }
+    // ---- prologue: R-1 stages in flight, then the first fragments of stage 0
     // (r04, measured and dropped -- tools/ab_latency.sh, profiles/r04_latency_anatomy.txt: issuing exactly as many stage loads
     // as a workgroup runs stages, instead of letting the cursor park on the last stage and re-load it R-1 times, with waits that
     // count the loads really younger: one tile 4.00 -> 4.20 ms, 64x64 2.83 -> 3.10 ms, the 32-tile step 82.2 -> 83.7 ms.  The
@@ -454,16 +402,6 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         cursor_next();
 #pragma unroll
         for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, (uint32_t)(r * G::STAGE_BYTES));
-        // keep every wave's instruction count per "stage" at PV: the first S2SR_L2PF prefetches ride here
-        if (G::PFW > 0) {
-            if (r < S2SR_L2PF) pf_next();
-#pragma unroll
-            for (int k = 0; k < G::PFW; ++k) pf_piece(k);
-        }
-    }
-    if (G::PFW > 0) {
-#pragma unroll
-        for (int r = R - 1; r < S2SR_L2PF; ++r) pf_next();        // (only when the prefetch runs further ahead than R-1 prologue rounds)
     }
     uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
     if (kAnat) p.trace[(size_t)blockIdx.x * 24 + 2] = __builtin_amdgcn_s_memtime();
@@ -549,10 +487,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const uint32_t dma_off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
         const char* sb = smem + cur_off;
         const char* sn = smem + next_off;
-        // conv5 (kPull): the first stage of every patch but the first finds its DMA quota already issued by the epilogue before it
-        const bool pulled = kPull && FIRST && !first_patch;
         if (!PROD) cursor_next();                                 // the stage R-1 ahead: its DMA rides on this stage
-        if (G::PFW > 0) pf_next();                                // and S2SR_L2PF stages beyond it: L2 prefetch
 #pragma unroll
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
@@ -596,18 +531,17 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sn + abase + ((dy * 3) * CT + ct) * 1024);
             }
-            if (kTrunk && CAP >= 0 && t >= 1 && t <= 2 * NP) {
-                const int np = (t - 1) >> 1, half = (t - 1) & 1;
-                hi_cap[CAP < 0 ? 0 : CAP][np][half] = *(const u32x2*)(sb + (cbase ^ (half * 16)) + np * G::ROWB);
+            if constexpr (kTrunk && CAP >= 0) {
+                if (t >= 1 && t <= 2 * NP) {
+                    const int np = (t - 1) >> 1, half = (t - 1) & 1;
+                    hi_cap[CAP][np][half] = *(const u32x2*)(sb + (cbase ^ (half * 16)) + np * G::ROWB);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
                 if ((sl * (G::T - 3)) / G::PW == t && !PROD) dma_piece(sl, dma_off);
-#pragma unroll
-            for (int k = 0; k < G::PFW; ++k)
-                if (((2 * k + 1) * (G::T - 3)) / (2 * G::PFW) == t) pf_piece(k);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int np = s - dy;
@@ -717,15 +651,6 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                     asm_land(lo_old[ct][np]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // kPull: the next patch's first stage would refill the slot of the stage just finished; do it now (that stage then
-        // issues nothing), so the ring stays full while this wave converts and stores.  Behind the row waits of rdb3 (below).
-        auto pull_burst = [&]() __attribute__((always_inline)) {
-            const uint32_t off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
-            cursor_next();
-#pragma unroll
-            for (int sl = 0; sl < G::PW; ++sl) dma_piece(sl, off);
-        };
-        if (kPull && !kRR) pull_burst();
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             if (kRR) {
@@ -735,7 +660,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 if (np + 1 < NP) load_skip((np + 1) & 1, sn, ln, opix[np + 1]);
                 if (np > 0) {
                     if (np + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR + SR) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR + (kPull ? G::PW : 0)) : "memory");   // + the pulled DMA quota (below)
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SR) : "memory");
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
@@ -744,7 +669,6 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) asm_land(rlo[kRR ? np & 1 : 0][kRR ? ct : 0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kPull && np == NP - 2) pull_burst();          // every skip request is out: nothing later waits behind these
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -1353,7 +1277,7 @@ __global__ void __launch_bounds__((WV + PROD) * 64, PROD ? 1 : WV / 4) conv_trun
             if (!PROD && t >= G::T - 3) {
 #pragma unroll
                 for (int i = 0; i < G::PWW; ++i)
-                    if (G::T - 3 + (i * 3) / G::PWW == t) dma_wts(i);
+                    if (G::T - 3 + (i * 3) / (G::PWW > 0 ? G::PWW : 1) == t) dma_wts(i);
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -1610,10 +1534,15 @@ hipError_t launch_trunk8_t(const ConvParams& p, hipStream_t st) {
 // ct = 1: conv1..4 (EPI_LRELU); ct = 2: conv5 (EPI_RDB5 / EPI_RDB5_RRDB).  Returns hipErrorNotSupported for
 // anything else.
 hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t st, bool trace, int force_form) {
+#if !S2SR_EXPERIMENTAL
+    if (trace || force_form == 4 || (p.f16_form & 1)) return hipErrorNotSupported;     // stamped builds, loader-wave form: experimental library only
+#endif
     if (ct == 1 && epi == EPI_LRELU) {
         if (force_form == 1) return launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);      // per-layer parity hook: name the patch form
         if (force_form == 2) return launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
+#if S2SR_EXPERIMENTAL
         if (force_form == 4) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);
+#endif
         if (force_form == 5) return launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
         if (force_form == 6) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);    // whole-patch forms (invalid-value on ragged sizes / mosaics)
         if (force_form == 7) return launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st);
@@ -1626,19 +1555,26 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         // is launch-bound: 351 dependent launches; S2SR_SMALL8=0 keeps the 16x32 form)
         const bool full = !trace && p.mos_py == 0 && p.H % 32 == 0 && p.W % 32 == 0 && !(p.f16_form & 4);   // whole patches only (f16_form bit 2: diagnostic off switch)
         const bool plain = !trace && p.mos_py == 0 && !(p.f16_form & 4);                                  // ragged, but no mosaic: the extent test alone
+#if S2SR_EXPERIMENTAL
         if (n32 < 96 && trace) return launch_trunk_t<1, 2, 7, EPI_LRELU, true>(p, st);               // launch anatomy of the single-tile form
+#endif
         if (n32 < 96 && !trace && !(p.f16_form & 2))
             return full ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st)
                         : plain ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
         if (n32 < 192 && !trace)
             return full ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st)
                         : plain ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
+#if S2SR_EXPERIMENTAL
         if (!trace && (p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
+#endif
         if (full) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);
         if (plain && !(p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 3>(p, st);
         if (!trace && !(p.f16_form & 4) && p.mos_py == 277 && p.mos_ry == 276 && p.mos_px == 277 && p.mos_rx == 276)
             return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 2>(p, st);                             // mosaics of 276-pixel windows (tile 256, pad 10)
-        return trace ? launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st) : launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
+#if S2SR_EXPERIMENTAL
+        if (trace) return launch_trunk_t<1, 8, 3, EPI_LRELU, true>(p, st);
+#endif
+        return launch_trunk_t<1, 8, 3, EPI_LRELU, false>(p, st);
     }
     // conv5: 16x32 patches (4 rows per wave, 4-deep ring); single tiles take 8x32 patches (2 rows per wave, 5-deep ring): one
     // 256x256 tile is 128 patches of 16x32 -- half the CUs idle through twelve MFMA-bound stages (r04 kernel trace: 24 us per
@@ -1648,8 +1584,10 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         const long n16 = (long)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.N;
         const bool small = force_form == 5 || (force_form == 0 && n16 < 192 && !(p.f16_form & 2));
         if (epi == EPI_RDB5) {
-            if (small) return trace ? launch_trunk_t<2, 2, 5, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 2, 5, EPI_RDB5, false>(p, st);
-            return trace ? launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);
+#if S2SR_EXPERIMENTAL
+            if (trace) return small ? launch_trunk_t<2, 2, 5, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st);
+#endif
+            return small ? launch_trunk_t<2, 2, 5, EPI_RDB5, false>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, false>(p, st);
         }
         return small ? launch_trunk_t<2, 2, 5, EPI_RDB5_RRDB, false>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5_RRDB, false>(p, st);
     }
@@ -1709,12 +1647,18 @@ hipError_t launch_conv_trunk_f8(const ConvParams& p, int ct, int epi, hipStream_
         // diagnostic suggested (that one read zeros as weights, and an MFMA fed zeros draws less power: the chip clocked higher).
         // The loader-wave form (conv_trunk_f8 PROD) is the default: 77.5 against 79.8 us per conv1-4 launch of 32 tiles on one box,
         // A/B/A/B (+3 %; the no-MFMA floor of either form is 58 us).  S2SR_FP8_LOADER=0 selects the four-wave forms below.
+#if S2SR_EXPERIMENTAL
         const bool w8 = (p.f8_form & 8) != 0, loader = (p.f8_form & 1) == 0;
         const int stream_w = (p.f8_form >> 1) & 3;
         if (w8) return launch_trunk8_t<1, 2, 6, EPI_LRELU, 8>(p, st);
-        if (loader) return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4, 1>(p, st) : launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 0, 1>(p, st);
-        if (stream_w == 1 || (stream_w == 0 && p.nstage > 4)) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
-        return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4>(p, st) : launch_trunk8_t<1, 4, 4, EPI_LRELU, 4, 6>(p, st);
+        if (!loader) {
+            if (stream_w == 1 || (stream_w == 0 && p.nstage > 4)) return launch_trunk8_t<1, 4, 6, EPI_LRELU>(p, st);
+            return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4>(p, st) : launch_trunk8_t<1, 4, 4, EPI_LRELU, 4, 6>(p, st);
+        }
+#else
+        if (p.f8_form != 0) return hipErrorNotSupported;      // the other conv1-4 forms: experimental library only
+#endif
+        return p.nstage <= 4 ? launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 4, 1>(p, st) : launch_trunk8_t<1, 4, 6, EPI_LRELU, 4, 0, 1>(p, st);
     }
     if (ct == 2 && epi == EPI_RDB5) return launch_trunk8_t<2, 4, 4, EPI_RDB5>(p, st);
     if (ct == 2 && epi == EPI_RDB5_RRDB) return launch_trunk8_t<2, 4, 4, EPI_RDB5_RRDB>(p, st);

@@ -146,6 +146,7 @@ struct s2sr_handle {
     bool f16_full = true;         // S2SR_F16_FULL=0: fp16 conv1-4 never take the whole-patch form (no px_live arithmetic in the epilogue) on 32-multiple launches
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
+    bool no_subpixel = false;     // experimental build, S2SR_NO_SUBPIXEL: up-convs in the upsample-on-load 3x3 form instead of the sub-pixel form
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     // paste maps of the window plan last stitched through s2sr_stitch_rows_u8_dev (row map, column map), kept on the device:
     // an AOI is stitched band by band, the maps are uploaded once per (H, W, tile, pad)
@@ -758,6 +759,17 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
     return S2SR_OK;
 }
 
+#if !S2SR_EXPERIMENTAL
+}  // namespace
+// the experimental kernel families are not in this library (s2sr_internal.h): their entry points answer "not supported"
+namespace s2sr {
+hipError_t launch_conv_trunk_wino(const ConvParams&, hipStream_t) { return hipErrorNotSupported; }
+size_t conv_wpack_bytes_wino(int cin, int cout) { return conv_wpack_bytes(cin, cout); }
+hipError_t launch_pack_trunk_wino(const float*, int, int, void*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_conv_trace(const ConvParams&, int, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace s2sr
+namespace {
+#endif
 }  // namespace
 
 // ==========================================================================================
@@ -765,7 +777,13 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
 // ==========================================================================================
 extern "C" {
 
-const char* s2sr_version(void) { return "s2sr 0.1 (gfx950, fp16-MFMA implicit-GEMM conv)"; }
+const char* s2sr_version(void) {
+#if S2SR_EXPERIMENTAL
+    return "s2sr 0.4 (gfx950, fp16-MFMA implicit-GEMM conv) +experimental";
+#else
+    return "s2sr 0.4 (gfx950, fp16-MFMA implicit-GEMM conv)";
+#endif
+}
 
 int s2sr_device_count(void) {
     int n = 0;
@@ -808,19 +826,27 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
         delete h;
         return fail(nullptr, S2SR_E_HIP, "hipStreamCreate failed");
     }
+    // The ten run-time switches of the shipped library (each fixed at creation, reported by s2sr_debug_get_config, each with a
+    // byte-identity or tolerance test): S2SR_GRAPH, S2SR_MOSAIC, S2SR_SMALL8, S2SR_F16_FULL, S2SR_LAST_FOLD, S2SR_D2H_STAGED,
+    // S2SR_FP8_TAIL, S2SR_LO_EXP, S2SR_FP8_XEXP, S2SR_FP8_GEXP.
     if (const char* g = getenv("S2SR_GRAPH")) h->graphs_on = atoi(g) != 0;
-    if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_MOSAIC")) h->mosaic_on = atoi(g) != 0;
-    if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
     if (const char* g = getenv("S2SR_SMALL8")) h->small8 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_F16_FULL")) h->f16_full = atoi(g) != 0;
     if (const char* g = getenv("S2SR_LAST_FOLD")) h->last_fold = atoi(g) != 0;
-    if (const char* g = getenv("S2SR_TAIL_W4")) h->tail_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_D2H_STAGED")) h->d2h_staged_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
+#if S2SR_EXPERIMENTAL
+    // kernel forms the measurements buried: only in the experimental build (s2sr_internal.h)
+    if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_TAIL_W4")) h->tail_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_LOADER")) h->fp8_form |= atoi(g) != 0 ? 0 : 1;
     if (const char* g = getenv("S2SR_FP8_WSTREAM")) h->fp8_form |= (atoi(g) & 3) << 1;
     if (const char* g = getenv("S2SR_FP8_W8")) h->fp8_form |= atoi(g) != 0 ? 8 : 0;
+    if (const char* g = getenv("S2SR_WINO")) h->trunk_wino = atoi(g) == 2 ? 2 : (atoi(g) != 0 ? 1 : 0);
+    h->no_subpixel = getenv("S2SR_NO_SUBPIXEL") != nullptr;
+#endif
     if (const char* g = getenv("S2SR_LO_EXP")) {
         const int v = atoi(g);
         if (v >= 6 && v <= 18) h->lo_exp = v;
@@ -828,7 +854,6 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     h->fp8_x_exp0 = h->fp8_x_exp; h->fp8_g_exp0 = h->fp8_g_exp;
-    if (const char* g = getenv("S2SR_WINO")) h->trunk_wino = atoi(g) == 2 ? 2 : (atoi(g) != 0 ? 1 : 0);
     if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
@@ -967,7 +992,7 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
             tmp.resize(wb);
             if (f8) pack_conv_weights_f8hp(pw, s.cin, s.cout, tmp.data(), last_fold);
             else pack_conv_weights(pw, s.cin, s.cout, nseg, tmp.data(), fold);
-            if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !getenv("S2SR_NO_SUBPIXEL")) {   // conv_up1, conv_up2
+            if (s.cin == 64 && s.cout == 64 && (idx + 4 == nconv || idx + 3 == nconv) && !h->no_subpixel) {   // conv_up1, conv_up2
                 const size_t pb = conv_wpack_bytes_phase(s.cin, s.cout);
                 std::vector<char> ph(pb);
                 for (int k = 0; k < 2; ++k) {
@@ -2058,7 +2083,11 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     p.wpack = d_w; p.bias = d_b; p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
     p.T = T; p.R = Rr; p.F = Rr; p.trash = h->d_trash;
     p.xh_in = T; p.lo_exp = h->lo_exp;   // conv_trunk_f16: trunk lo coming in (here read and written in place: timing only)
+#if S2SR_EXPERIMENTAL
     p.dbg = getenv("S2SR_DBG") ? atoi(getenv("S2SR_DBG")) : 0;
+#else
+    if (trace && trace_wgs > 0) return fail(h, S2SR_E_INVALID, "stamped kernel builds are in the experimental library only (make EXP=1, S2SR_LIB=.../libs2sr_exp.so)");
+#endif
     int epi;
     if (cout == 32) { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_LRELU; }
     else { p.dst = D1; p.dst_img = 12 * blk; epi = EPI_RDB5; }

@@ -6,6 +6,15 @@
 
 #include "../../include/s2sr.h"
 
+// Kernel families and forms that the measurements buried (profiles/r0x_*) are compiled only with -DS2SR_EXPERIMENTAL=1
+// (`make EXP=1` -> csrc/libs2sr_exp.so, selected with S2SR_LIB=...): the row-Winograd trunk form (conv_wino.hip, +-0..+1.5 % in
+// the net), the fp16 loader-wave form (+-0), the one-wave-per-SIMD tail convs (10-15 % slower), the 8-wave RDB path (r01's
+// kernel), the non-default fp8 conv1-4 forms, the upsample-on-load up-convs, and every stamped (TRACE) build.  The default
+// library answers requests for them with hipErrorNotSupported and ignores their environment switches.
+#ifndef S2SR_EXPERIMENTAL
+#define S2SR_EXPERIMENTAL 0
+#endif
+
 namespace s2sr {
 
 // ------------------------------------------------------------------------------------------

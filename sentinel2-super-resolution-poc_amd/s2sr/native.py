@@ -167,6 +167,12 @@ def load_library():
     return lib
 
 
+def experimental() -> bool:
+    """Is the loaded library the experimental build (make EXP=1 -> libs2sr_exp.so: the kernel forms the measurements buried
+    and every stamped build)?  The shipped library answers requests for those with an error."""
+    return b"+experimental" in load_library().s2sr_version()
+
+
 def tiff_lzw_encode(data) -> bytes:
     """Host call (no GPU): raw strip bytes -> TIFF LZW.  ctypes drops the GIL: strips encode in parallel."""
     lib = load_library()

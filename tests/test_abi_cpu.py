@@ -143,13 +143,13 @@ def test_hidden_asm_loads_are_not_touched_before_their_wait(tmp_path):
     if not Path(hipcc).exists():
         pytest.skip("no hipcc")
     csrc = REPO / "sentinel2-super-resolution-poc_amd" / "csrc"
-    for src in ("conv_trunk.hip", "conv3x3.hip", "conv_wino.hip"):
+    for src in ("conv_trunk.hip", "conv3x3.hip"):        # the shipped kernels (conv_wino.hip is in the experimental library only: tools/check_exp.sh)
         asm = tmp_path / (src + ".s")
         subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
                         "--cuda-device-only", str(csrc / src), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
         r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_loads.py"), str(asm)], capture_output=True, text=True)
         assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:]
-        if src != "conv_wino.hip":       # (the Winograd form has inline MFMAs but no hidden loads: only the wait-state check applies)
+        if src == "conv_trunk.hip":      # the check has something to check (conv3x3.hip's hidden loads sat in the RDB epilogues: experimental library now)
             assert asm.read_text().count("global_load_dwordx2 a[") + asm.read_text().count("global_load_dwordx4 a[") > 0
 
 

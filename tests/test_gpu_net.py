@@ -466,14 +466,21 @@ def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir):
         assert cfg["lo_exp"] == lo_exp and cfg["trunk_w4"] == 1, cfg
         outs[lo_exp] = e.forward_f32(g["x"])
         e.close()
-    e = _fresh(monkeypatch, 23, HP, {"S2SR_TRUNK": "0"})
-    assert e.debug_config()["trunk_w4"] == 0
-    outs["w8"] = e.forward_f32(g["x"])
-    e.close()
+    if native.experimental():       # the 8-wave path (r01's kernel) is in the experimental library only
+        e = _fresh(monkeypatch, 23, HP, {"S2SR_TRUNK": "0"})
+        assert e.debug_config()["trunk_w4"] == 0
+        outs["w8"] = e.forward_f32(g["x"])
+        e.close()
+    else:                            # the shipped library ignores the switch
+        e = _fresh(monkeypatch, 23, HP, {"S2SR_TRUNK": "0", "S2SR_WINO": "1", "S2SR_TAIL_W4": "1", "S2SR_F16_LOADER": "1"})
+        cfg = e.debug_config()
+        assert cfg["trunk_w4"] == 1 and cfg["trunk_wino"] == 0 and cfg["tail_w4"] == 0 and cfg["f16_loader"] == 0, cfg
+        e.close()
     errs = {k: float(np.abs(v - g["y_b23"]).max()) for k, v in outs.items()}
     print("trunk lo as e4m3 * 2^k / fp16 lo on the 8-wave path: max-abs err " + ", ".join(f"{k}: {v:.3e}" for k, v in errs.items()))
     assert all(v <= TOL_HP for k, v in errs.items() if k != 16) and errs[16] <= 1e-3, errs
-    assert errs["w8"] <= 1.5 * errs[12]
+    if "w8" in errs:
+        assert errs["w8"] <= 1.5 * errs[12]
     # different arithmetic must give different bytes (r02's version of this test compared one cached handle with itself)
     keys = list(outs)
     for i in range(len(keys)):
@@ -484,6 +491,7 @@ def test_trunk_lo_as_e4m3_scale_choices(monkeypatch, golden_dir):
     assert np.array_equal(engine(23, HP).forward_f32(g["x"]), outs[12])
 
 
+@pytest.mark.experimental
 def test_row_winograd_trunk_goldens(monkeypatch, golden_dir):
     """S2SR_WINO=1: RDB conv1-4 in the row-Winograd F(2,3) form (conv_wino.hip).  Its transformed operands are rounded to
     fp16 once more than the direct form's; the HP bound must hold all the same (CPU emulation: tools/emulate_r03.py), on the
@@ -572,6 +580,7 @@ def test_conv_last_folded_and_eight_stage_forms(monkeypatch, golden_dir):
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
 
 
+@pytest.mark.experimental
 def test_tail_convs_one_wave_per_simd_form_gives_the_same_bytes(monkeypatch, golden_dir):
     """S2SR_TAIL_W4 picks the 4-wave instantiations of the split-operand tail convs (conv_up1 / conv_up2 sub-pixel forms, conv_hr,
     conv_last; conv3x3.hip F8 schedule with WAVES = 4 and twice the rows per wave).  Same patch, same ring, same accumulation
@@ -672,6 +681,7 @@ def test_whole_patch_conv_forms_change_no_byte(monkeypatch):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.experimental
 def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
     """S2SR_TRUNK=0 keeps the RDB convs on the 8-wave kernel (conv3x3.hip EPI_RDB5 / EPI_RDB5_RRDB epilogues, fp16 lo,
     3-buffer workspace): the g3 / g4 / g5 goldens in HP and fast mode through a handle created with the switch set."""
@@ -687,6 +697,7 @@ def test_eight_wave_rdb_path_goldens(monkeypatch, golden_dir):
             assert err <= tol, (prec, nb, err)
 
 
+@pytest.mark.experimental
 def test_subpixel_and_upsample_on_load_forms_agree(monkeypatch):
     """The up-convs run in sub-pixel form (2x2 taps on the source image); S2SR_NO_SUBPIXEL=1 keeps the
     3x3-on-upsampled loader form.  Both must match the oracle, and each other to fp32-rounding level."""
@@ -898,6 +909,7 @@ def test_fp8_mode_full_tile_and_batch_properties():
 
 @pytest.mark.parametrize("env,form", [({"S2SR_FP8_LOADER": "0"}, 1), ({"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "1"}, 3),
                                       ({"S2SR_FP8_LOADER": "0", "S2SR_FP8_WSTREAM": "2"}, 5), ({"S2SR_FP8_W8": "1"}, 8)])
+@pytest.mark.experimental
 def test_fp8_conv14_kernel_forms_agree_bit_for_bit(monkeypatch, env, form):
     """The fp8 conv1-4 kernel comes in several forms (a fifth load-only wave or not, weights streamed or resident in LDS,
     one or two waves per SIMD).  They accumulate the same products in the same order, so whichever form the environment

@@ -2,6 +2,8 @@
 # A/B of a conv_trunk.hip compile-time switch on ONE box, single-tile latency and the 32-tile step: tools/ab_latency.sh MACRO "v1 v2"
 M=$1; VALS=$2
 C=sentinel2-super-resolution-poc_amd/csrc
+# the variants are built over the shipped objects: put the shipped library back on ANY exit (r03 ADVICE: an interrupted run left a diagnostic build where the tests load it)
+trap 'rm -f $C/conv_trunk.o; make -C $C > /dev/null 2>&1' EXIT
 for rep in 1 2; do
 for v in $VALS; do
   rm -f $C/conv_trunk.o
@@ -11,4 +13,3 @@ for v in $VALS; do
   timeout -k 10 200 python3 tools/quick_bench.py --batch 32 --steps 4 --hp 1 2>&1 | grep -E "B=|rdb_conv"
 done
 done
-rm -f $C/conv_trunk.o; make -C $C > /dev/null 2>&1

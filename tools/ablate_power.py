@@ -6,6 +6,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
+os.environ.setdefault("S2SR_LIB", str(REPO / "sentinel2-super-resolution-poc_amd" / "csrc" / "libs2sr_exp.so"))   # stamped builds: make -C csrc EXP=1
 sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
 from s2sr import native  # noqa: E402
 from s2sr.weights import synthetic_state_dict  # noqa: E402

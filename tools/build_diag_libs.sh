@@ -9,8 +9,8 @@ set -e
 C=sentinel2-super-resolution-poc_amd/csrc
 make -C $C > /dev/null
 mkdir -p $C/diag
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -Wno-unused-value -ffp-contract=off"
-OBJS="engine.o conv_trunk.o conv_wino.o pack.o postprocess.o hostcodec.o tiles.o"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-result -Wno-unused-value -ffp-contract=off -DS2SR_EXPERIMENTAL=0"
+OBJS="engine.o conv_trunk.o pack.o postprocess.o hostcodec.o tiles.o"
 build() {  # name, define
   /opt/rocm/bin/hipcc $FLAGS $2 -c $C/conv3x3.hip -o $C/diag/conv3x3_$1.o
   (cd $C && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o diag/libs2sr_$1.so $OBJS diag/conv3x3_$1.o)

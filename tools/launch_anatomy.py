@@ -12,6 +12,7 @@ import numpy as np
 
 os.environ["S2SR_DBG"] = "32"
 REPO = Path(__file__).resolve().parent.parent
+os.environ.setdefault("S2SR_LIB", str(REPO / "sentinel2-super-resolution-poc_amd" / "csrc" / "libs2sr_exp.so"))   # stamped builds: make -C csrc EXP=1
 sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
 import torch  # noqa: E402,F401
 from s2sr import native  # noqa: E402

@@ -7,6 +7,7 @@ import numpy as np
 os.environ["S2SR_DBG"] = "16"
 os.environ["S2SR_TRACE_TIMED"] = "1"
 REPO = Path(__file__).resolve().parent.parent
+os.environ.setdefault("S2SR_LIB", str(REPO / "sentinel2-super-resolution-poc_amd" / "csrc" / "libs2sr_exp.so"))   # stamped builds: make -C csrc EXP=1
 sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
 from s2sr import native
 e = native.Engine(num_block=1, precision=native.PREC_F16_HP)

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Stamp breakdown of the ring kernel's first stages (diagnostic build)."""
+import os
 import sys
 from pathlib import Path
 import numpy as np
 REPO = Path(__file__).resolve().parent.parent
+os.environ.setdefault("S2SR_LIB", str(REPO / "sentinel2-super-resolution-poc_amd" / "csrc" / "libs2sr_exp.so"))   # stamped builds: make -C csrc EXP=1
 sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
 from s2sr import native
 
