@@ -85,21 +85,28 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int CT_, int NP_, int R_>
+// WGL (r04 A/B; measured 3.4 % SLOWER, profiles/r04_wgl_ab.txt: experimental library only): the weights do NOT travel through the LDS-DMA ring.  Every wave fetches the 9 * CT A
+// fragments of the NEXT stage with global_load_dwordx4 straight into AGPRs (two register sets, ping-pong; the accumulators of
+// the conv1-4 forms live in architectural VGPRs, so the AGPRs are free), one stage ahead.  A stage in LDS is then the slab plane
+// alone: 20 % fewer LDS-DMA bytes and instructions, 23 % fewer LDS reads, and room for one more ring slot.
+template <int CT_, int NP_, int R_, int WGL_ = 0>
 struct TG {
-    static constexpr int CT = CT_, NP = NP_, R = R_, WAVES = 4;
+    static constexpr int CT = CT_, NP = NP_, R = R_, WAVES = 4, WGL = WGL_;
     static constexpr int TH = WAVES * NP, TW = 32, SW = TW + 2, SH = TH + 2, SPX = SH * SW;
     static constexpr int ROWB = SW * 32;                       // bytes of one slab row
     static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
-    static constexpr int PI = PLANE / 1024, WI = 9 * CT, NSTI = PI + WI;
+    static constexpr int PI = PLANE / 1024, WI = 9 * CT, NSTI = PI + (WGL ? 0 : WI);
     static constexpr int PW = (NSTI + WAVES - 1) / WAVES;      // LDS-DMA instructions per wave and stage
     static constexpr int STAGE_BYTES = NSTI * 1024;
     static constexpr int RING_BYTES = R * STAGE_BYTES;
     static constexpr int BIAS_OFF = RING_BYTES;
     static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
     static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per stage
-    static constexpr int PV = PW;                              // vector-memory instructions per wave and stage (r02's L2-prefetch lanes, measured -5..-15 %, are gone)
-    static constexpr int NW = PV * (R - 2);                    // ... that may stay in flight at a barrier
+    static constexpr int PV = PW + (WGL ? WI : 0);             // vector-memory instructions per wave and stage (WGL: + the A-fragment loads)
+    // ... that may stay in flight at a barrier.  WGL: the A fragments of the next stage were requested at the start of this one
+    // and must have landed: only this stage's own DMA pieces, issued behind them, may still fly
+    static constexpr int NW = WGL ? PW : PV * (R - 2);
+    static constexpr int NW0 = WGL ? PW * (R - 2) : NW;        // the prologue's wait: stage 0 (and its A fragments, requested first) landed
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static constexpr int AK = (3 * CT + NP + 1) / (NP + 2);    // A fragments fetched per step: the 3 * CT of the next kernel column must fit the NP + 2 steps of this one
     static_assert(3 * CT <= AK * (NP + 2), "the A fragments of a kernel column must fit its steps");
@@ -180,6 +187,14 @@ __device__ __forceinline__ void mfma_first_v(f32x16& acc, const f16x8& a, const 
 __device__ __forceinline__ void mfma_first_bias_v(f32x16& acc, const f16x8& a, const f16x8& b, const f32x16& bias) {
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(bias));
 }
+// ... and with the A operand in AGPRs (WGL: the weights are loaded there straight from global memory; gfx90a+ MFMAs take A / B
+// from either file)
+__device__ __forceinline__ void mfma_acc_va(f32x16& acc, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first_bias_va(f32x16& acc, const f16x8& a, const f16x8& b, const f32x16& bias) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "a"(a), "v"(b), "v"(bias));
+}
 template <typename T>
 __device__ __forceinline__ void asm_land_v(T& r) { asm volatile("" : "+v"(r)); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -217,9 +232,10 @@ struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3
 // FULL == 3: ragged launches without mosaics (any image that is no multiple of the patch): the extent test alone.
 // FULL == 2: mosaics of the reference's default windows (256 + 2 x 10 = 276 pixels, period 277, at the trunk's scale): the separator
 // test on compile-time constants -- the 8 scalars of the runtime geometry are what pushes the generic form over its SGPR budget.
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0>
 __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const ConvParams p) {
-    using G = TG<CT, NP, R>;
+    using G = TG<CT, NP, R, WGL>;
+    static_assert(WGL == 0 || (EPI == EPI_LRELU && !TRACE && PROD == 0), "weights-from-global form: conv1-4 only");
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert(EPI == EPI_LRELU || kTrunk, "trunk kernel: conv1-4 (LRELU) and conv5 (RDB5 / RDB5_RRDB) only");
     static_assert(PROD == 0 || (EPI == EPI_LRELU && !TRACE), "loader wave: conv1-4 form only");
@@ -391,12 +407,25 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     }
     f16x8 acol[3][3][CT];     // A fragments: [kernel column dx][kernel row dy][cout tile]
     f16x8 breg[6];            // B fragments of steps t, t+1, t+2, t+3 (ring indexed by step % 6)
+    // WGL: the A fragments of two stages in AGPRs, [set][tap * CT + ct]; set = stage parity inside the patch (NS is even)
+    f16x8 aw[WGL ? 2 : 1][WGL ? 9 * CT : 1];
+    const char* const wlane = (const char*)p.wpack + (size_t)lane * 16;
+    auto issue_a = [&](auto set_tag, int st) __attribute__((always_inline)) {     // stage st of a patch -> register set
+        constexpr int SET = decltype(set_tag)::value;
+        if constexpr (WGL != 0) {
+            const char* a = wlane + (size_t)st * (G::WI * 1024);
+#pragma unroll
+            for (int f = 0; f < 9 * CT; ++f)
+                aw[SET][f] = __builtin_bit_cast(f16x8, asm_load16(a + (size_t)f * 1024));     // (through the helper: an asm operand that names a captured array inside a generic lambda does not compile)
+        }
+    };
 
     // ---- prologue: R-1 stages in flight, then the first fragments of stage 0
     // (r04, measured and dropped -- tools/ab_latency.sh, profiles/r04_latency_anatomy.txt: issuing exactly as many stage loads
     // as a workgroup runs stages, instead of letting the cursor park on the last stage and re-load it R-1 times, with waits that
     // count the loads really younger: one tile 4.00 -> 4.20 ms, 64x64 2.83 -> 3.10 ms, the 32-tile step 82.2 -> 83.7 ms.  The
     // redundant loads cost nothing measurable; the run-time wait selection and its scalar state do.)
+    if (WGL) issue_a(std::integral_constant<int, 0>{}, 0);          // the first stage's weights, in front of everything
 #pragma unroll
     for (int r = 0; r < (PROD ? 0 : R - 1); ++r) {
         cursor_next();
@@ -406,7 +435,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     uint32_t cur_off = 0;                                         // LDS offset of the slot of the stage being computed
     if (kAnat) p.trace[(size_t)blockIdx.x * 24 + 2] = __builtin_amdgcn_s_memtime();
     if (PROD) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the loader waited for the data (vmcnt: my bias request)
-    else wait_release_barrier<G::NW>();                           // stage 0 has landed
+    else wait_release_barrier<G::NW0>();                          // stage 0 has landed
     if (kAnat) p.trace[(size_t)blockIdx.x * 24 + 3] = __builtin_amdgcn_s_memtime();
     // the bias requests are older than every DMA instruction: they have landed too.  conv5 reads it from LDS in its epilogue
     // (every stage barrier lies in between), conv1-4 feed it to the first MFMA of each accumulator as C.
@@ -430,10 +459,12 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     }
     {
         const char* sb = smem;
+        if (!WGL) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3) * CT + ct) * 1024);
+                for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3) * CT + ct) * 1024);
+        }
 #pragma unroll
         for (int v = 0; v < 3; ++v) breg[v] = *(const f16x8*)(sb + bbase[0] + v * G::ROWB);
     }
@@ -480,9 +511,12 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 
     // One stage.  FIRST: first stage of a patch (accumulators start from C = 0; the barrier inside it may also
     // leave the previous patch's epilogue stores in flight).  CAP >= 0: capture x block CAP for the trunk epilogue.
-    auto stage = [&](auto first_tag, auto cap_tag, bool first_patch) __attribute__((always_inline)) {
+    auto stage = [&](auto first_tag, auto cap_tag, bool first_patch, auto set_tag, int st_next) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr int CAP = decltype(cap_tag)::value;
+        constexpr int SET = decltype(set_tag)::value;             // WGL: the register set this stage's A fragments sit in
+        static_assert(!WGL || (kAccV && kBiasC), "WGL: accumulators in VGPRs, bias as C");
+        if (WGL) issue_a(std::integral_constant<int, SET ^ 1>{}, st_next);     // the next stage's, one stage ahead (other set)
         const uint32_t next_off = (cur_off + G::STAGE_BYTES == (uint32_t)G::RING_BYTES) ? 0u : cur_off + G::STAGE_BYTES;
         const uint32_t dma_off = (cur_off == 0) ? (uint32_t)(G::RING_BYTES - G::STAGE_BYTES) : cur_off - G::STAGE_BYTES;
         const char* sb = smem + cur_off;
@@ -494,7 +528,9 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             if (t == G::T - 3) {
                 // next stage landed + this slot released; everything below reads the NEXT slot
                 constexpr int NST = TrunkStores<EPI, CT, NP>::value;
-                constexpr int NEPI = (G::NW + NST < 63) ? G::NW + NST : 63;
+                // (WGL: the A fragments requested at the top of this stage are YOUNGER than the previous epilogue's stores and must
+                // have landed: no allowance for the stores)
+                constexpr int NEPI = WGL ? G::NW : ((G::NW + NST < 63) ? G::NW + NST : 63);
                 if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // my only vector-memory traffic are stores
                 else if (FIRST && !first_patch) wait_release_barrier<NEPI>();
                 else wait_release_barrier<G::NW>();
@@ -516,7 +552,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 else breg[u % 6] = *(const f16x8*)(sn + bbase[0] + (u - G::T) * G::ROWB);
             }
             // A fragments: the next kernel column's, one per step; behind the barrier the next stage's column 0
-            if (dx < 2) {
+            if (dx < 2 && !WGL) {
 #pragma unroll
                 for (int k = 0; k < G::AK; ++k) {             // AK = 1 in every form but the 8x32-patch conv5 (6 fragments, 4 steps)
                     const int f = s * G::AK + k;
@@ -526,7 +562,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                     }
                 }
             }
-            if (t >= G::T - 3) {
+            if (t >= G::T - 3 && !WGL) {
                 const int dy = t - (G::T - 3);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sn + abase + ((dy * 3) * CT + ct) * 1024);
@@ -565,6 +601,12 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                         continue;
                     }
 #endif
+                    if (WGL) {
+                        const f16x8& af = aw[WGL ? SET : 0][WGL ? (dy * 3 + dx) * CT + ct : 0];
+                        if (FIRST && dx == 0 && dy == 0) mfma_first_bias_va(acc[ct][np], af, breg[t % 6], bacc[kBiasC ? ct : 0]);
+                        else mfma_acc_va(acc[ct][np], af, breg[t % 6]);
+                        continue;
+                    }
                     if (kAccV) {
                         if (FIRST && dx == 0 && dy == 0) {
                             if (kBiasC) mfma_first_bias_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
@@ -796,16 +838,29 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const bool first_patch = it == 0;
         if (TRACE && p.trace && (p.dbg & 16) && lane == 0 && it == 2) p.trace[(size_t)blockIdx.x * 24 + 8 + wave] = __builtin_amdgcn_s_memtime();   // epilogue of patch 1 left
         if (kTrunk) {   // NS >= 4 (host): stages 0..3 are the 64 channels of x
-            stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch);
-            stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false);
-            stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false);
-            stage(integral_constant<bool, false>{}, integral_constant<int, 3>{}, false);
-            for (int st = 4; st < NS - 1; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+            constexpr integral_constant<int, 0> S0{};
+            stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch, S0, 0);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false, S0, 0);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false, S0, 0);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 3>{}, false, S0, 0);
+            for (int st = 4; st < NS - 1; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
             prefetch_lo(it);                                      // NS >= 5 (host): the last stage is peeled, the loads ride on it
-            stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+            stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
+        } else if (WGL) {
+            // the register set is the stage's parity inside the patch (NS is even: every patch starts on set 0)
+            constexpr integral_constant<int, 0> S0{};
+            constexpr integral_constant<int, 1> S1{};
+            constexpr integral_constant<int, -1> NC{};
+            stage(integral_constant<bool, true>{}, NC, first_patch, S0, 1);
+            stage(integral_constant<bool, false>{}, NC, false, S1, 2 == NS ? 0 : 2);
+            for (int st = 2; st < NS; st += 2) {
+                stage(integral_constant<bool, false>{}, NC, false, S0, st + 1);
+                stage(integral_constant<bool, false>{}, NC, false, S1, st + 2 == NS ? 0 : st + 2);
+            }
         } else {
-            stage(integral_constant<bool, true>{}, integral_constant<int, -1>{}, first_patch);
-            for (int st = 1; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false);
+            constexpr integral_constant<int, 0> S0{};
+            stage(integral_constant<bool, true>{}, integral_constant<int, -1>{}, first_patch, S0, 0);
+            for (int st = 1; st < NS; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
         }
         if (kAnat && it == my_tiles - 1) p.trace[(size_t)blockIdx.x * 24 + 4] = __builtin_amdgcn_s_memtime();
         epilogue(it);
@@ -823,15 +878,16 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     }
 }
 
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0>
 hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
-    using G = TG<CT, NP, R>;
+    using G = TG<CT, NP, R, WGL>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::NW < 64, "vmcnt field is 6 bits");
     if (FULL == 1 && (p.mos_py != 0 || p.H % G::TH != 0 || p.W % 32 != 0)) return hipErrorInvalidValue;
+    if (WGL && (p.nstage & 1)) return hipErrorInvalidValue;       // the A-fragment register sets alternate with the stage's parity
     if (FULL == 3 && p.mos_py != 0) return hipErrorInvalidValue;
     if (FULL == 2 && (p.mos_py != 277 || p.mos_ry != 276 || p.mos_px != 277 || p.mos_rx != 276)) return hipErrorInvalidValue;
-    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL>;
+    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL, WGL>;
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -1547,6 +1603,11 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         if (force_form == 6) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);    // whole-patch forms (invalid-value on ragged sizes / mosaics)
         if (force_form == 7) return launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st);
         if (force_form == 8) return launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st);
+#if S2SR_EXPERIMENTAL
+        if (force_form == 9) return launch_trunk_t<1, 8, 4, EPI_LRELU, false, 0, 1, 1>(p, st);   // whole 32x32 patches, weights from global memory (WGL)
+#else
+        if (force_form == 9) return hipErrorNotSupported;
+#endif
         // 32x32 patches (8 rows per wave, 3-deep ring) unless that leaves most CUs without a patch (single tiles):
         // then 16x32 patches (4 rows per wave, 5-deep ring) spread the image over twice as many workgroups.  Both
         // forms accumulate in the same order, so the result does not depend on the choice.
@@ -1566,6 +1627,9 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
                         : plain ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
 #if S2SR_EXPERIMENTAL
         if (!trace && (p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 1>(p, st);     // S2SR_F16_LOADER=1: loader-wave form
+#endif
+#if S2SR_EXPERIMENTAL
+        if (full && (p.f16_form & 8)) return launch_trunk_t<1, 8, 4, EPI_LRELU, false, 0, 1, 1>(p, st);   // r04 A/B: weights from global memory, 4-deep slab ring
 #endif
         if (full) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);
         if (plain && !(p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 3>(p, st);

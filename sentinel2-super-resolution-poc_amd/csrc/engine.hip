@@ -147,6 +147,7 @@ struct s2sr_handle {
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool no_subpixel = false;     // experimental build, S2SR_NO_SUBPIXEL: up-convs in the upsample-on-load 3x3 form instead of the sub-pixel form
+    bool f16_wgl = false;         // S2SR_F16_WGL=1 (r04 A/B): fp16 conv1-4 of whole-patch launches fetch their weights from global memory into AGPRs (conv_trunk_f16 WGL)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     // paste maps of the window plan last stitched through s2sr_stitch_rows_u8_dev (row map, column map), kept on the device:
     // an AOI is stitched band by band, the maps are uploaded once per (H, W, tile, pad)
@@ -374,7 +375,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
         return S2SR_OK;
     }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
-        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4);
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4) | (h->f16_wgl ? 8 : 0);
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
         if (e != hipErrorNotSupported) HIPCHK(h, e);
@@ -837,6 +838,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_D2H_STAGED")) h->d2h_staged_on = atoi(g) != 0;
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
 #if S2SR_EXPERIMENTAL
+    if (const char* g = getenv("S2SR_F16_WGL")) h->f16_wgl = atoi(g) != 0;
     // kernel forms the measurements buried: only in the experimental build (s2sr_internal.h)
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;
@@ -1840,6 +1842,7 @@ int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     out->precision = h->cfg.precision; out->group = h->cfg.group; out->trunk_w4 = h->trunk_w4 ? 1 : 0; out->lo_exp = h->lo_exp;
     out->fp8_form = h->fp8_form; out->fp8_x_exp = h->fp8_x_exp; out->fp8_g_exp = h->fp8_g_exp; out->fp8_hp_tail = h->fp8_hp_tail ? 1 : 0;
     out->graphs_on = h->graphs_on ? 1 : 0; out->trunk_wino = h->trunk_wino; out->reserved[0] = h->mosaic_on ? 1 : 0; out->reserved[1] = h->f16_loader ? 1 : 0; out->reserved[2] = h->last_fold ? 1 : 0; out->reserved[3] = h->tail_w4 ? 1 : 0; out->reserved[4] = h->f16_full ? 1 : 0; out->reserved[5] = (int32_t)h->ws_allocs;
+    out->trunk_wino |= h->f16_wgl ? 0x100 : 0;      // (bit 8 of trunk_wino: the WGL A/B switch took)
     return S2SR_OK;
 }
 
