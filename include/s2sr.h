@@ -142,6 +142,12 @@ int  s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int3
  * (cnn_super_resolution.py:217-280): HxWx3 u8 -> 4Hx4Wx3 u8, channel order as given. */
 int  s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
                      int32_t tile, int32_t pad, uint8_t* out);
+/* The device work of one /api/wow or /api/sr job in ONE call (apply_wow_sr, wow_sr.py:85-110; apply_farm_sr, farm_sr.py:156-178):
+ * RGB image in -> cvtColor RGB2BGR -> RealESRGAN.enhance -> BGR2RGB -> the crop-visibility post-process (prm; NULL: none) ->
+ * RGB image out.  Same bytes as s2sr_enhance_u8 on the swapped image followed by s2sr_postprocess_u8; one upload and one
+ * download instead of three round trips and two host-side channel flips of the 16x image. */
+int  s2sr_enhance_job_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, int32_t tile, int32_t pad,
+                         const s2sr_pp_params* prm, uint8_t* out_rgb);
 /* float image before quantisation (HWC fp32), for parity tests of the tiled path */
 int  s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W,
                       int32_t tile, int32_t pad, float* out);

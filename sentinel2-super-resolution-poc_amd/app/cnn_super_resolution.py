@@ -273,6 +273,17 @@ class RealESRGAN:
             raise TypeError(f"expected uint8 image, got {img.dtype}")
         return self._engine.enhance_u8(img, tile=self.tile_size, pad=self.tile_pad)
 
+    def enhance_job(self, rgb: np.ndarray, post=None) -> np.ndarray:
+        """What a job does around `enhance` (wow_sr.py:85-110, farm_sr.py:156-178) in one native call: RGB in, RGB2BGR, the net,
+        BGR2RGB, the crop-visibility post-process `post` (native.pp_wow() / pp_farm(); None: none), RGB out.  The same bytes as
+        `enhance(rgb[:, :, ::-1])[:, :, ::-1]` followed by the post-process -- one upload and one download instead of three
+        round trips and two host-side channel flips of the 16x image (tests/test_gpu_app.py)."""
+        if rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise ValueError(f"expected HxWx3 image, got shape {rgb.shape}")
+        if rgb.dtype != np.uint8:
+            raise TypeError(f"expected uint8 image, got {rgb.dtype}")
+        return self._engine.enhance_job_u8(rgb, post, tile=self.tile_size, pad=self.tile_pad)
+
     def _tile_process(self, img: torch.Tensor) -> torch.Tensor:
         """[1,3,H,W] float in [0,1] -> [1,3,4H,4W] float32 through the tiled path (:236-280)."""
         u8 = (img[0].permute(1, 2, 0).cpu().numpy() * 255.0).round().clip(0, 255).astype(np.uint8)

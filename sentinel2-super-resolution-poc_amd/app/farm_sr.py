@@ -48,18 +48,21 @@ def apply_farm_sr(input_path: Path, output_path: Path, scale: int = 4) -> Tuple[
     from app.cnn_super_resolution import thread_precision
     with thread_precision(os.environ.get("S2SR_FARM_PRECISION") or None):
         esrgan = RealESRGAN(scale=scale, tile_size=256)
-        sr_rgb = np.ascontiguousarray(esrgan.enhance(np.ascontiguousarray(img[:, :, ::-1]))[:, :, ::-1])
-    final = _pp_engine().postprocess_u8(sr_rgb, native.pp_farm())    # the three steps of :170-178 fused
+        if hasattr(esrgan, "enhance_job"):      # RGB2BGR -> net -> BGR2RGB -> the three steps of :170-178, one native call
+            final = esrgan.enhance_job(img, native.pp_farm())
+        else:
+            sr_rgb = np.ascontiguousarray(esrgan.enhance(np.ascontiguousarray(img[:, :, ::-1]))[:, :, ::-1])
+            final = _pp_engine().postprocess_u8(sr_rgb, native.pp_farm())
 
     output_path = Path(output_path)
     output_path.parent.mkdir(parents=True, exist_ok=True)
     output_png = output_path.with_suffix(".png")
     if georef is not None:
         final_output = output_path.with_suffix(".tif")
-        rio.write_geotiff_rgb(final_output, final, georef.scaled(scale))
+        rio.write_outputs(final, output_png, final_output, georef.scaled(scale))
     else:
         final_output = output_png
-    rio.write_png(output_png, final)
+        rio.write_png(output_png, final)
     metadata = {
         "input_file": str(input_path),
         "output_file": str(final_output),

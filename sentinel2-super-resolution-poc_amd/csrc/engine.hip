@@ -1290,9 +1290,16 @@ int s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, i
     return S2SR_OK;
 }
 
+static int postprocess_dev_locked(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W, const s2sr_pp_params* prm,
+                                  void* d_out, hipStream_t st);
+
+// job_rgb: the caller's image is RGB and wants RGB back -- R and B are swapped on the device in front of and behind the net (the
+// reference's cvtColor pair, wow_sr.py:85,103).  prm: the crop-visibility post-process (wow_sr.py:187-209) on the stitched RGB
+// image, on the device, before the one copy out (it is image-global: no band leaves before the whole mosaic is done).
 static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int tile, int pad, uint8_t* out_u8,
-                        float* out_f32, bool force_tiled = false) {
+                        float* out_f32, bool force_tiled = false, bool job_rgb = false, const s2sr_pp_params* prm = nullptr) {
     if (!h || !img || (!out_u8 && !out_f32) || H <= 0 || W <= 0 || tile <= 0 || pad < 0) return S2SR_E_INVALID;
+    if ((job_rgb || prm) && !out_u8) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
@@ -1302,6 +1309,8 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
     if ((rc = ensure_scratch(h, 0, ib))) return rc;
     if ((rc = ensure_scratch(h, 1, opx * (out_f32 ? 4 : 1)))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], img, ib, hipMemcpyHostToDevice, st));
+    if (job_rgb) HIPCHK(h, launch_swap_rb_u8((const uint8_t*)h->d_scratch[0], (size_t)H * W, (uint8_t*)h->d_scratch[0], st));
+    const bool whole_finish = job_rgb || prm != nullptr;      // the image leaves in one piece, behind the device-side finish
     const bool tiled = force_tiled || (long long)H * W > (long long)tile * tile * 4;   // strict '>' (:226)
     if (!tiled) {
         if (out_f32) {
@@ -1405,7 +1414,7 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             chunk_r0.push_back(ny);
         }
         const int nchunks = (int)chunk_r0.size() - 1;
-        if (!out_f32 && nchunks > 1) {
+        if (!out_f32 && nchunks > 1 && !whole_finish) {
             const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
             while ((int)h->group_done.size() < nchunks) {
                 hipEvent_t e;
@@ -1449,6 +1458,16 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
         if (out_f32) HIPCHK(h, launch_stitch_f32((const float*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (float*)h->d_scratch[1], st));
         else HIPCHK(h, launch_stitch_u8((const uint8_t*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm, d_cm, OH, OW, (uint8_t*)h->d_scratch[1], st));
     }
+    const uint8_t* d_final = (const uint8_t*)h->d_scratch[1];
+    if (whole_finish) {
+        if (job_rgb) HIPCHK(h, launch_swap_rb_u8((const uint8_t*)h->d_scratch[1], (size_t)OH * OW, (uint8_t*)h->d_scratch[1], st));
+        if (prm) {
+            // the windows' output buffer is free again once the stitch has read it; whole-image jobs get a buffer of their own
+            if ((rc = ensure_scratch(h, 4, opx))) return rc;
+            if ((rc = postprocess_dev_locked(h, h->d_scratch[1], 1, OH, OW, prm, h->d_scratch[4], st))) return rc;
+            d_final = (const uint8_t*)h->d_scratch[4];
+        }
+    }
     if (h->group_done.empty()) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1456,13 +1475,20 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
     }
     HIPCHK(h, hipEventRecord(h->group_done[0], st));
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[0], 0));
-    if ((rc = d2h_staged(h, out_f32 ? (uint8_t*)out_f32 : out_u8, (const uint8_t*)h->d_scratch[1], opx * (out_f32 ? 4 : 1), true))) return rc;
+    if ((rc = d2h_staged(h, out_f32 ? (uint8_t*)out_f32 : out_u8, out_f32 ? (const uint8_t*)h->d_scratch[1] : d_final, opx * (out_f32 ? 4 : 1), true))) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     return S2SR_OK;
 }
 
 int s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, uint8_t* out) {
     return enhance_impl(h, img, H, W, tile, pad, out, nullptr);
+}
+
+// A whole /api/wow job's device work in one call (apply_wow_sr, wow_sr.py:85-110): RGB image in, RGB2BGR, RealESRGAN.enhance,
+// BGR2RGB, _enhance_for_crops (prm != NULL), RGB image out -- one upload, one download, nothing in between on the host.
+int s2sr_enhance_job_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, int32_t tile, int32_t pad, const s2sr_pp_params* prm,
+                        uint8_t* out_rgb) {
+    return enhance_impl(h, rgb, H, W, tile, pad, out_rgb, nullptr, false, true, prm);
 }
 
 int s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {

@@ -324,6 +324,21 @@ hipError_t launch_absmax_e4m3(const void* d, size_t n_bytes, int exp2, float* d_
     return hipGetLastError();
 }
 
+// R <-> B of a u8 HWC image, in place or into another buffer: the reference feeds the net BGR and turns its output back
+// (cv2.cvtColor RGB2BGR / BGR2RGB, wow_sr.py:85,103)
+__global__ void swap_rb_kernel(const uint8_t* __restrict__ in, size_t npx, uint8_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t r = in[3 * i], g = in[3 * i + 1], b = in[3 * i + 2];
+        out[3 * i] = b; out[3 * i + 1] = g; out[3 * i + 2] = r;
+    }
+}
+
+hipError_t launch_swap_rb_u8(const uint8_t* d_in, size_t npx, uint8_t* d_out, hipStream_t st) {
+    const int grid = (int)((npx + 255) / 256 > 8192 ? 8192 : (npx + 255) / 256);
+    hipLaunchKernelGGL(swap_rb_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, d_in, npx, d_out);
+    return hipGetLastError();
+}
+
 __global__ void gather_windows_kernel(const uint8_t* __restrict__ img, int H, int W, const int32_t* __restrict__ rects,
                                       int T, int wh, int ww, uint8_t* __restrict__ tiles) {
     const size_t total = (size_t)T * wh * ww * 3;

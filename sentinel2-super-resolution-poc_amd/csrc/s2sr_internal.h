@@ -209,6 +209,7 @@ hipError_t launch_pack_f32_nchw(const float* d_x, int N, int C, int H, int W, fl
                                 int Hp, int Wp, hipStream_t st);
 hipError_t launch_trunk_to_fp8(const char* hi, size_t hi_img, const char* lo, size_t lo_img, int lo_e4m3_exp, int N, int Hp, int Wp, char* out,
                                hipStream_t st);
+hipError_t launch_swap_rb_u8(const uint8_t* d_in, size_t npx, uint8_t* d_out, hipStream_t st);
 hipError_t launch_gather_windows(const uint8_t* d_img, int H, int W, const int32_t* d_rects, int T, int wh, int ww,
                                  uint8_t* d_tiles, hipStream_t st);
 hipError_t launch_stitch_u8(const uint8_t* d_tiles, int tilesX, int oth, int otw, const int32_t* d_rowmap,

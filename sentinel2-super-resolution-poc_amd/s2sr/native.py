@@ -86,6 +86,7 @@ _PROTOS = {
                                             C.c_void_p]),
     "s2sr_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_enhance_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_enhance_job_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
     "s2sr_enhance_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tile_process_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_cut_windows_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p, C.c_void_p]),
@@ -247,47 +248,63 @@ def _ptr(a: np.ndarray):
 class _PinnedPool:
     """Page-locked output arrays (s2sr_host_alloc).  `RealESRGAN.enhance` returns a fresh numpy array per call
     (cnn_super_resolution.py:231-233); a fresh pageable array costs the device-to-host path a staging copy and a page fault per
-    4 KB (805 MB: 130 ms), a page-locked one is filled by the DMA engines (20 ms).  Pinning is slow, so buffers are recycled:
-    an array handed out here returns its buffer to the pool when the last view of it is garbage collected; at most
-    S2SR_PINNED_POOL_MB (default 4096) of idle buffers are kept.  S2SR_PINNED_OUT=0 turns it off (plain np.empty)."""
+    4 KB (805 MB: 130 ms), a page-locked one is filled by the DMA engines (20 ms).  Pinning is slow (hundreds of ms for 800 MB), so
+    buffers are recycled: an array handed out here returns its buffer to the pool when the last view of it is garbage collected.
+    Buffers come in 16-MB size classes, so images of nearby sizes share them (r03 ADVICE: exact-size keys pinned a new buffer
+    per distinct image size).  Two caps: S2SR_PINNED_POOL_MB (default 4096) of IDLE buffers are kept, and S2SR_PINNED_MAX_MB
+    (default 16384) bounds all page-locked bytes, in use and idle -- beyond it `empty` hands out ordinary pageable arrays (the
+    library then takes its staged route).  A service that RETAINS results (job tables, caches) should copy them (`.copy()`) or
+    set S2SR_PINNED_OUT=0: a retained result keeps its page-locked buffer."""
+    BUCKET = 16 << 20
 
     def __init__(self):
         import threading
         self._lock = threading.Lock()
-        self._free = {}          # nbytes -> [address, ...]
+        self._free = {}          # bucket bytes -> [address, ...]
         self._idle = 0
+        self._total = 0          # page-locked bytes alive, in use + idle
         self._cap = int(os.environ.get("S2SR_PINNED_POOL_MB", "4096")) << 20
+        self._max = int(os.environ.get("S2SR_PINNED_MAX_MB", "16384")) << 20
         self.on = os.environ.get("S2SR_PINNED_OUT", "1") != "0"
-        self.hits = self.misses = 0
+        self.hits = self.misses = self.refused = 0
 
     def empty(self, shape, dtype) -> np.ndarray:
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         if not self.on or n < (8 << 20):
             return np.empty(shape, dtype=dtype)
+        nb = -(-n // self.BUCKET) * self.BUCKET
         lib = load_library()
         with self._lock:
-            lst = self._free.get(n)
+            lst = self._free.get(nb)
             addr = lst.pop() if lst else None
             if addr is not None:
-                self._idle -= n
+                self._idle -= nb
                 self.hits += 1
+            elif self._total + nb > self._max:
+                self.refused += 1
+                return np.empty(shape, dtype=dtype)
+            else:
+                self._total += nb           # reserved before the (slow) allocation, outside the lock
+                self.misses += 1
         if addr is None:
             p = C.c_void_p()
-            if lib.s2sr_host_alloc(n, C.byref(p)) or not p.value:
+            if lib.s2sr_host_alloc(nb, C.byref(p)) or not p.value:
+                with self._lock:
+                    self._total -= nb
                 return np.empty(shape, dtype=dtype)      # no page-locked memory to be had: the pageable route still works
             addr = p.value
-            self.misses += 1
-        buf = (C.c_uint8 * n).from_address(addr)
-        weakref.finalize(buf, self._give, addr, n)        # runs when the last numpy view of `buf` is gone
-        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+        buf = (C.c_uint8 * nb).from_address(addr)
+        weakref.finalize(buf, self._give, addr, nb)       # runs when the last numpy view of `buf` is gone
+        return np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
 
-    def _give(self, addr, n):
+    def _give(self, addr, nb):
         with self._lock:
-            if self._idle + n <= self._cap:
-                self._free.setdefault(n, []).append(addr)
-                self._idle += n
+            if self._idle + nb <= self._cap:
+                self._free.setdefault(nb, []).append(addr)
+                self._idle += nb
                 return
+            self._total -= nb
         try:
             load_library().s2sr_host_free(C.c_void_p(addr))
         except Exception:
@@ -296,10 +313,11 @@ class _PinnedPool:
     def trim(self):
         """Release every idle buffer."""
         with self._lock:
-            addrs = [a for lst in self._free.values() for a in lst]
+            addrs = [(a, nb) for nb, lst in self._free.items() for a in lst]
             self._free.clear()
             self._idle = 0
-        for a in addrs:
+            self._total -= sum(nb for _, nb in addrs)
+        for a, _ in addrs:
             load_library().s2sr_host_free(C.c_void_p(a))
 
 
@@ -392,6 +410,16 @@ class Engine:
         assert c == 3
         out = pinned_pool.empty((4 * H, 4 * W, 3), np.uint8)
         self._check(self._lib.s2sr_enhance_u8(self._h, _ptr(img), H, W, tile, pad, _ptr(out)), "s2sr_enhance_u8")
+        return out
+
+    def enhance_job_u8(self, rgb: np.ndarray, prm: Optional[PPParams] = None, tile: int = 256, pad: int = 10) -> np.ndarray:
+        """RGB in -> (BGR) net -> RGB -> post-process `prm` (None: none) -> RGB out: a job's device work in one call."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        H, W, c = rgb.shape
+        assert c == 3
+        out = pinned_pool.empty((4 * H, 4 * W, 3), np.uint8)
+        self._check(self._lib.s2sr_enhance_job_u8(self._h, _ptr(rgb), H, W, tile, pad, C.byref(prm) if prm is not None else None, _ptr(out)),
+                    "s2sr_enhance_job_u8")
         return out
 
     def enhance_f32(self, img: np.ndarray, tile: int = 256, pad: int = 10) -> np.ndarray:

@@ -129,11 +129,14 @@ def _adler32_combine(a1: int, a2: int, len2: int) -> int:
     return (s2 << 16) | s1
 
 
-def encode_png(img: np.ndarray, level: int = 3, band_rows: int = 128, workers: Optional[int] = None) -> bytes:
+def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None, strategy: Optional[int] = None) -> bytes:
     """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> PNG bytes.  The SR outputs are tens of megapixels and PNG
     deflate is what a job spends most of its time in, so the image is cut into bands that are filtered
     (Sub) and deflated on a thread pool (zlib releases the GIL), each band ending on a sync flush so
-    that the pieces concatenate into one valid zlib stream (the pigz construction)."""
+    that the pieces concatenate into one valid zlib stream (the pigz construction).
+    Encoder settings = what `cv2.imwrite(path, img)` uses when the reference calls it without parameters (wow_sr.py:156,163;
+    OpenCV 4.x grfmt_png.cpp: filter Sub, Z_BEST_SPEED, strategy Z_RLE): level 1 + Z_RLE, the fast end of deflate (r03 used
+    level 3 with the default strategy: 118 ms of a 279 ms job for a 4096x4096 image).  Any setting decodes to the same pixels."""
     import struct
     import zlib
     from concurrent.futures import ThreadPoolExecutor
@@ -154,7 +157,7 @@ def encode_png(img: np.ndarray, level: int = 3, band_rows: int = 128, workers: O
         raw[:, 1:c + 1] = blk[:, :c]
         raw[:, c + 1:] = blk[:, c:] - blk[:, :-c]
         data = raw.tobytes()
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_RLE if strategy is None else strategy)
         out = co.compress(data) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
         return out, zlib.adler32(data), len(data)
 
@@ -180,6 +183,25 @@ def encode_png(img: np.ndarray, level: int = 3, band_rows: int = 128, workers: O
 
 def write_png(path: Path, rgb: np.ndarray) -> None:
     Path(path).write_bytes(encode_png(rgb))
+
+
+def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoRef") -> None:
+    """The GeoTIFF and the PNG of one job (wow_sr.py:126-164) written side by side: two threads, each a pool over strips /
+    bands of the same array (zlib and the native LZW encoder release the GIL)."""
+    import threading
+    err = []
+
+    def run(fn, *a):
+        try:
+            fn(*a)
+        except BaseException as e:      # surfaced below: a failed writer must fail the job
+            err.append(e)
+    t = threading.Thread(target=run, args=(write_geotiff_rgb, tif_path, rgb, georef))
+    t.start()
+    run(write_png, png_path, rgb)
+    t.join()
+    if err:
+        raise err[0]
 
 
 def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_strip: int = 64) -> None:

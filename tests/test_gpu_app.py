@@ -304,3 +304,30 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     ao = d["aoi_strong_scaling"]
     assert ao["n_gpus"] == 2 and ao["scaling"] == "strong" and ao["value"] > 0 and ao["rccl_ranks_seen"] == 2
     assert "blocks of 8 per rank" in ao["workload"]
+
+
+def test_enhance_job_equals_the_separate_steps(monkeypatch, tmp_path):
+    """s2sr_enhance_job_u8 (RealESRGAN.enhance_job: RGB in, RGB2BGR, the net, BGR2RGB, the post-process, RGB out -- one upload, one
+    download) gives the bytes of the reference's own sequence (wow_sr.py:85-110: cvtColor, enhance, cvtColor, _enhance_for_crops)
+    run as separate calls -- on the whole-image branch, on the tiled branch (banded copies off: the post-process is image-global),
+    with the wow and the farm constants and without a post-process; and the PNG / GeoTIFF written side by side decode to it."""
+    import app.cnn_super_resolution as m
+    from s2sr import native
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    e = m.RealESRGAN(model_name="realesrgan_anime", tile_size=256)
+    rng = np.random.default_rng(21)
+    for (H, W) in ((96, 130), (540, 610)):          # whole image; 3 x 3 windows of 276 with shifted edges
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        rgb[..., 1] = np.maximum(rgb[..., 1], 90)
+        sr_rgb = np.ascontiguousarray(e.enhance(np.ascontiguousarray(rgb[:, :, ::-1]))[:, :, ::-1])
+        assert np.array_equal(e.enhance_job(rgb, None), sr_rgb), (H, W)
+        for prm in (native.pp_wow(), native.pp_farm()):
+            want = e._engine.postprocess_u8(sr_rgb, prm)
+            got = e.enhance_job(rgb, prm)
+            assert np.array_equal(got, want), (H, W, prm.blur_sigma)
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)})
+    rio.write_outputs(got, tmp_path / "o.png", tmp_path / "o.tif", geo)
+    back, g = rio.read_rgb_u8(tmp_path / "o.tif")
+    assert np.array_equal(back, got) and g.pixel_size == (2.5, 2.5)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "o.png").convert("RGB")), got)

@@ -646,6 +646,13 @@ def test_page_locked_outputs_are_recycled_and_equal_the_pageable_route():
     gc.collect()
     c = e.enhance_u8(img, tile=256, pad=10)          # ... and now the first one comes back
     assert pool.hits == h0 + 1 and np.array_equal(c, b)
+    # 16-MB size classes: an image of a nearby size takes a recycled buffer instead of pinning another one
+    del b
+    gc.collect()
+    m1, h1 = pool.misses, pool.hits
+    c2 = e.enhance_u8(img[:, :890], tile=256, pad=10)
+    assert pool.misses == m1 and pool.hits == h1 + 1 and c2.shape == (2800, 3560, 3) and c2.flags.c_contiguous
+    del c2
     pool.on = False
     try:
         d = e.enhance_u8(img, tile=256, pad=10)
@@ -653,7 +660,7 @@ def test_page_locked_outputs_are_recycled_and_equal_the_pageable_route():
         pool.on = True
     assert np.array_equal(d, c)
     c[0, 0, 0] ^= 1                                   # writable like any ndarray
-    del b, c
+    del c
     gc.collect()
     pool.trim()
 
