@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/prof_r03.sh <name>
+# usage (on the GPU box, from the repo root): tools/prof_r04.sh <name>
 #   -> gpurun_out/<name>/: rocprofv3 kernel-trace stats of `bench.py` (hp and fp8 lines) + separate PMC passes
 #      (one counter group per pass, as MI355X_MICROARCH.md prescribes) on one group of 16 tiles per mode,
 #      then tools/summarize_prof.py -> summary.txt and pmc_summary.json
