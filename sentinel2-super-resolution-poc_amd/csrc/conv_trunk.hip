@@ -232,7 +232,9 @@ struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3
 // FULL == 3: ragged launches without mosaics (any image that is no multiple of the patch): the extent test alone.
 // FULL == 2: mosaics of the reference's default windows (256 + 2 x 10 = 276 pixels, period 277, at the trunk's scale): the separator
 // test on compile-time constants -- the 8 scalars of the runtime geometry are what pushes the generic form over its SGPR budget.
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0>
+// LOE: conv5's lo encoding in its short form (the shipped one) or its long form (experimental library: the byte-identity test
+// of the two, tests/test_gpu_trunk.py::test_f16_conv5_lo_encoding_forms_agree).
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC>
 __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const ConvParams p) {
     using G = TG<CT, NP, R, WGL>;
     static_assert(WGL == 0 || (EPI == EPI_LRELU && !TRACE && PROD == 0), "weights-from-global form: conv1-4 only");
@@ -776,10 +778,11 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                     if (kTrunk) {
                         // lo = v - fp16(v), kept as e4m3(lo * 2^lo_exp): 4 significant bits of it are what the 1e-3 needs
                         // (measured: max-abs 8.8e-5 .. 1.85e-4 against 7.0e-5 .. 1.8e-4 with an fp16 lo, 2.2e-3 .. 3.4e-3 without one)
-                        // (plain C++ on purpose: the same arithmetic as fma(fp16(v), -2^lo_exp, v * 2^lo_exp) through an asm v_fma_mix_f32
-                        // is bit-identical in isolation -- tools/scratch/mix_test.hip -- but inside this kernel measured 1.4e-3 on the
-                        // stress net instead of 1.3e-4, for a reason not found; not worth 100 instructions per patch)
-#if S2SR_F16_LOENC
+                        // Two forms with the same bytes (test_f16_conv5_lo_encoding_forms_agree, experimental library, stress weights).
+                        // (r02 tried another short form -- fma(fp16(v), -2^lo_exp, v * 2^lo_exp) as one asm v_fma_mix_f32 -- that measured
+                        // 1.4e-3 instead of 1.3e-4 inside this kernel although it was bit-identical in isolation; never explained, and
+                        // not this form: here the fma computes v - fp16(v), exact in fp32, and the scale rides in the conversion.)
+                        if constexpr (LOE != 0) {
                         // r03: 2.5 instead of 4.5 instructions per value (the conv5 epilogue was 1/3 lo encoding): v - fp16(v) in ONE
                         // v_fma_mix_f32 that reads the packed half in place (exact: the difference of a float and its own fp16 rounding),
                         // the clamp on the unscaled value, and the 2^lo_exp inside v_cvt_scalef32_pk_fp8_f32 (it divides by the power
@@ -798,7 +801,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                         w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[0], q[1], lo_dec, false);
                         w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w8, q[2], q[3], lo_dec, true);
                         lq8[g] = __builtin_bit_cast(uint32_t, w8);
-#else
+                        } else {
                         float q[4];
                         {
                             const f16x4 hv4 = __builtin_bit_cast(f16x4, hpk[g]);
@@ -809,7 +812,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                         int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
                         w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w8, true);
                         lq8[g] = (uint32_t)w8;
-#endif
+                        }
                     }
                 }
                 // pair the half-waves: one 16-B store per 16-channel block, 1 KiB contiguous per wave-instruction
@@ -878,7 +881,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     }
 }
 
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC>
 hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     using G = TG<CT, NP, R, WGL>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
@@ -887,7 +890,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     if (WGL && (p.nstage & 1)) return hipErrorInvalidValue;       // the A-fragment register sets alternate with the stage's parity
     if (FULL == 3 && p.mos_py != 0) return hipErrorInvalidValue;
     if (FULL == 2 && (p.mos_py != 277 || p.mos_ry != 276 || p.mos_px != 277 || p.mos_rx != 276)) return hipErrorInvalidValue;
-    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL, WGL>;
+    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL, WGL, LOE>;
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -1647,6 +1650,12 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
     if (ct == 2 && (epi == EPI_RDB5 || epi == EPI_RDB5_RRDB)) {
         const long n16 = (long)((p.W + 31) / 32) * ((p.H + 15) / 16) * p.N;
         const bool small = force_form == 5 || (force_form == 0 && n16 < 192 && !(p.f16_form & 2));
+#if S2SR_EXPERIMENTAL
+        if (force_form == 2)      // 16x32 patches with the LONG form of the lo encoding
+            return epi == EPI_RDB5 ? launch_trunk_t<2, 4, 4, EPI_RDB5, false, 0, 0, 0, 0>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5_RRDB, false, 0, 0, 0, 0>(p, st);
+#else
+        if (force_form == 2) return hipErrorNotSupported;
+#endif
         if (epi == EPI_RDB5) {
 #if S2SR_EXPERIMENTAL
             if (trace) return small ? launch_trunk_t<2, 2, 5, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st);

@@ -274,3 +274,23 @@ def test_f16_patch_forms_agree_bit_for_bit(eng):
         if native.experimental():
             assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=4)), Cin  # the loader-wave form: same stream of MFMAs
         assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=5)), Cin      # 8x32 patches
+
+
+@pytest.mark.experimental
+def test_f16_conv5_lo_encoding_forms_agree(eng):
+    """the shipped conv5 epilogue encodes the trunk's lo half in a short form (v_fma_mix_f32 for v - fp16(v), the
+    2^lo_exp inside v_cvt_scalef32_pk_fp8_f32); the long form (subtract, multiply, clamp, v_cvt_pk_fp8_f32) is form 2 of the
+    experimental library.  Same bytes out -- hi blocks and lo planes -- on ordinary operands and on stress operands whose lo
+    values reach the clamp (|lo| up to 448 * 2^-lo_exp) and the e4m3 subnormal range."""
+    rng = np.random.default_rng(77)
+    le = eng.debug_config()["lo_exp"]
+    for scale in (1.0, 40.0, 1e-3):
+        N, H, W = 2, 33, 70
+        x, w, b = _rand(rng, N, 192, 64, H, W)
+        x = _h(x * np.float32(scale))
+        lo = (rng.integers(-7, 8, size=(N, 64, H, W)) * 2.0 ** (-4 - le)).astype(np.float32)
+        skip = _h(rng.standard_normal((N, 64, H, W)).astype(np.float32) * np.float32(scale))
+        for kind, kw in ((K5, {}), (K5R, {"skip": skip})):
+            a = eng.debug_conv_trunk(kind, x, w, b, lo=lo, form=1, **kw)
+            c = eng.debug_conv_trunk(kind, x, w, b, lo=lo, form=2, **kw)
+            assert np.array_equal(a, c), (scale, kind, float(np.abs(a - c).max()))

@@ -1,6 +1,7 @@
 """CPU checks of the post-process oracle (oracle/postprocess_ref.py): published 8-bit OpenCV
 known answers and structural properties.  (Parity of this stage is UNPINNED: no cv2 here.)"""
 import numpy as np
+import pytest
 
 from oracle import postprocess_ref as pp
 
@@ -242,3 +243,46 @@ def test_gaussian_blur_tracks_the_float_definition():
         d = np.abs(pp.gaussian_blur_u8(img, sigma).astype(np.float64) - ref)
         # taps quantised to 1/256 (each up to ~0.9/256 off) on full-range noise: up to ~1.3 levels from the float blur, 0.3 on average
         assert d.max() <= 1.6 and d.mean() <= 0.45, (sigma, float(d.max()), float(d.mean()))
+
+
+def test_oracle_against_cv2_golden(golden_dir):
+    """The pin this oracle lacks (no cv2 in the build image, no reference-held fixture): when someone with an
+    OpenCV wheel has run tools/make_cv2_golden.py, tests/golden/g9_cv2_postprocess.npz holds every stage of the reference's
+    cv2 call chain (wow_sr.py:190-207, farm_sr.py:66-106) on this repo's test images and on the reference's own upload.  Each
+    oracle stage is then fed cv2's own previous stage (so a difference is not carried along) and must agree within 2 LSB; the
+    exact-match rate per stage is printed.  Skipped when the file is absent -- the oracle then stays "parity unpinned"."""
+    f = golden_dir / "g9_cv2_postprocess.npz"
+    if not f.exists():
+        pytest.skip("no cv2 golden (run tools/make_cv2_golden.py where opencv-contrib-python>=4.8.0 is installed)")
+    g = np.load(f)
+    names = sorted({k.split(".")[0] for k in g.files if k.endswith(".img")})
+    worst = {}
+    for name in names:
+        img = g[f"{name}.img"]
+        for tag, (clip, grid, sigma, w_img, w_blur, gain) in (("wow", (2.5, 8, 1.2, 1.4, -0.4, 1.2)), ("farm", (2.5, 8, 1.5, 2.2, -1.2, 1.3))):
+            ref = {k: g[f"{name}.{tag}.{k}"] for k in ("lab", "clahe_l", "contrast", "blur", "sharp", "hsv", "final")}
+            lab_cl = ref["lab"].copy()
+            lab_cl[..., 0] = ref["clahe_l"]
+            hsv_f = ref["hsv"].astype(np.float32)
+            mask = (hsv_f[..., 0] > 35) & (hsv_f[..., 0] < 85)
+            hsv_f[..., 1] = np.where(mask, np.clip(hsv_f[..., 1] * np.float32(gain), 0, 255), hsv_f[..., 1])
+            got = {
+                "lab": pp.rgb2lab_u8(img),
+                "clahe_l": pp.clahe_u8(ref["lab"][..., 0], clip, grid),
+                "contrast": pp.lab2rgb_u8(lab_cl),
+                "blur": pp.gaussian_blur_u8(ref["contrast"], sigma),
+                "sharp": pp.add_weighted_u8(ref["contrast"], w_img, ref["blur"], w_blur),
+                "hsv": pp.rgb2hsv_u8(ref["sharp"]),
+                "final": pp.hsv2rgb_u8(hsv_f.astype(np.uint8)),
+            }
+            for k in got:
+                d = np.abs(got[k].astype(np.int16) - ref[k].astype(np.int16))
+                if k == "hsv":          # hue wraps at 180
+                    d[..., 0] = np.minimum(d[..., 0], 180 - d[..., 0])
+                worst[k] = max(worst.get(k, 0), int(d.max()))
+                print(f"cv2 {g['cv2_version']} {name}/{tag}/{k}: max |d| {int(d.max())}, identical {np.mean(d == 0):.5f}")
+                assert d.max() <= 2, (name, tag, k, int(d.max()))
+            end = pp.enhance_for_crops(img) if tag == "wow" else pp.farm_postprocess(img)
+            d = np.abs(end.astype(np.int16) - ref["final"].astype(np.int16))
+            print(f"cv2 {name}/{tag}/end-to-end: max |d| {int(d.max())}, identical {np.mean(d == 0):.5f}")
+    print("worst per stage:", worst)
