@@ -280,8 +280,9 @@ int  s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, 
  * x is rounded to the operand format on the way in (fp16, or e4m3 at the handle's scales), so callers pass representable
  * values; `lo` ([N,64,H,W], kinds 1-2, may be NULL) is stored as e4m3(lo * 2^lo_exp); `skip` ([N,64,H,W]) as the
  * (fp16 hi, e4m3 lo) pair (kind 2) or fp16 (kind 5).  form: kind 0: 0 auto, 1 = 16x32 patches, 2 = 32x32 patches,
- * 3 = row-Winograd F(2,3), 4 = 32x32 patches with the load-only fifth wave, 5 = 8x32 patches (single tiles); kinds 1-2: 0 auto, 1 = 16x32
- * patches, 5 = 8x32 patches (single tiles); kind 3: the fp8_form bits. */
+ * 3 = row-Winograd F(2,3), 4 = 32x32 patches with the load-only fifth wave, 5 = 8x32 patches (single tiles), 10 = 8x32 patches with two
+ * planes per pipeline stage; kinds 1-2: 0 auto, 1 = 16x32 patches, 5 = 8x32 patches, 10 = 8x32 patches with two planes per stage; kind 3:
+ * the fp8_form bits.  (3, 4, 9 and the long lo-encoding form 2 of kinds 1-2: experimental library only.) */
 typedef struct s2sr_debug_trunk_args {
     int32_t kind, form;
     int32_t N, Cin, H, W;

@@ -56,6 +56,9 @@
 #ifndef S2SR_F16_LOENC
 #define S2SR_F16_LOENC 1   // conv_trunk_f16 conv5: the short form of the lo encoding (v_fma_mix_f32 + v_cvt_scalef32_pk_fp8_f32), see the epilogue
 #endif
+#ifndef S2SR_SMALL_PL
+#define S2SR_SMALL_PL 2         // conv_trunk_f16, the single-tile forms (8x32 patches): planes per pipeline stage (1: as until r04's first half)
+#endif
 #ifndef S2SR_F16_EARLYBIAS
 #define S2SR_F16_EARLYBIAS 1    // conv_trunk_f16: 1 = the bias is requested (inline-asm loads) before the ring fill and consumed behind the first
                                 // wait; 0 = plain C++ loads in front of the first DMA instruction, as until r03 (two dependent round trips)
@@ -89,19 +92,26 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // fragments of the NEXT stage with global_load_dwordx4 straight into AGPRs (two register sets, ping-pong; the accumulators of
 // the conv1-4 forms live in architectural VGPRs, so the AGPRs are free), one stage ahead.  A stage in LDS is then the slab plane
 // alone: 20 % fewer LDS-DMA bytes and instructions, 23 % fewer LDS reads, and room for one more ring slot.
-template <int CT_, int NP_, int R_, int WGL_ = 0>
+// PL (r04, the single-tile forms): planes per pipeline stage.  A stage of an 8x32 patch is 0.7 us for 0.28 us of MFMA work -- its
+// barrier, its LDS round trips and its DMA issue are per-stage costs (profiles/r04_latency_anatomy.txt) -- so the small forms take
+// TWO 16-channel planes (and their two weight blocks) per stage: half the barriers per patch, the same MFMAs in the same order.
+template <int CT_, int NP_, int R_, int WGL_ = 0, int PL_ = 1>
 struct TG {
-    static constexpr int CT = CT_, NP = NP_, R = R_, WAVES = 4, WGL = WGL_;
+    static constexpr int CT = CT_, NP = NP_, R = R_, WAVES = 4, WGL = WGL_, PL = PL_;
     static constexpr int TH = WAVES * NP, TW = 32, SW = TW + 2, SH = TH + 2, SPX = SH * SW;
     static constexpr int ROWB = SW * 32;                       // bytes of one slab row
     static constexpr int PLANE = ((SPX * 32 + 1023) / 1024) * 1024;
-    static constexpr int PI = PLANE / 1024, WI = 9 * CT, NSTI = PI + (WGL ? 0 : WI);
+    static constexpr int PI1 = PLANE / 1024, PI = PL * PI1;    // slab DMA pieces per plane / per stage
+    static constexpr int WI1 = 9 * CT, WI = PL * WI1;          // weight pieces (KiB) per plane / per stage
+    static constexpr int NSTI = PI + (WGL ? 0 : WI);
+    static constexpr int WOFF = PL * PLANE;                    // the stage's weight blocks sit behind its slab planes
     static constexpr int PW = (NSTI + WAVES - 1) / WAVES;      // LDS-DMA instructions per wave and stage
     static constexpr int STAGE_BYTES = NSTI * 1024;
     static constexpr int RING_BYTES = R * STAGE_BYTES;
     static constexpr int BIAS_OFF = RING_BYTES;
     static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
-    static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per stage
+    static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per plane
+    static constexpr int TS = PL * T;                          // ... per stage
     static constexpr int PV = PW + (WGL ? WI : 0);             // vector-memory instructions per wave and stage (WGL: + the A-fragment loads)
     // ... that may stay in flight at a barrier.  WGL: the A fragments of the next stage were requested at the start of this one
     // and must have landed: only this stage's own DMA pieces, issued behind them, may still fly
@@ -110,7 +120,8 @@ struct TG {
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static constexpr int AK = (3 * CT + NP + 1) / (NP + 2);    // A fragments fetched per step: the 3 * CT of the next kernel column must fit the NP + 2 steps of this one
     static_assert(3 * CT <= AK * (NP + 2), "the A fragments of a kernel column must fit its steps");
-    static_assert(PW <= T - 3, "DMA slots must fit in front of the barrier step");
+    static_assert(PW <= TS - 3, "DMA slots must fit in front of the barrier step");
+    static_assert(PL == 1 || WGL == 0, "");
 };
 
 // LDS-DMA, 16 B per lane (conv3x3.hip glds16).  FORCE_UNIFORM: the stamped diagnostic build's divergent stamp
@@ -234,9 +245,10 @@ struct TrunkStores {   // epilogue stores per wave (all unconditional, see conv3
 // test on compile-time constants -- the 8 scalars of the runtime geometry are what pushes the generic form over its SGPR budget.
 // LOE: conv5's lo encoding in its short form (the shipped one) or its long form (experimental library: the byte-identity test
 // of the two, tests/test_gpu_trunk.py::test_f16_conv5_lo_encoding_forms_agree).
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC, int PL = 1>
 __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const ConvParams p) {
-    using G = TG<CT, NP, R, WGL>;
+    using G = TG<CT, NP, R, WGL, PL>;
+    static_assert(PL == 1 || (!TRACE && PROD == 0), "two-plane stages: plain forms only");
     static_assert(WGL == 0 || (EPI == EPI_LRELU && !TRACE && PROD == 0), "weights-from-global form: conv1-4 only");
     constexpr bool kTrunk = (EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB);
     static_assert(EPI == EPI_LRELU || kTrunk, "trunk kernel: conv1-4 (LRELU) and conv5 (RDB5 / RDB5_RRDB) only");
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     const int ntiles = tpi * p.N;
     const int my_tiles = (ntiles - slot_in_round + nwg - 1) / nwg;
     if (my_tiles <= 0) return;                                   // workgroup-uniform
-    const int NS = p.nstage;
+    const int NS = p.nstage / PL;                                // stages per patch (of PL planes each)
     // dbg bit 5 (32): launch anatomy of a small launch (tools/launch_anatomy.py), wave 0 lane 0: [0] entry (s_memrealtime), [1] entry,
     // [2] prologue DMA issued, [3] first barrier passed (stage 0 landed), [4] last stage of the last patch done, [5] its epilogue's
     // stores issued, [6] exit after vmcnt(0) (all s_memtime), [7] exit (s_memrealtime)
@@ -281,12 +293,13 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         int j = wave + sl * 4;
         if (j > G::NSTI - 1) j = G::NSTI - 1;                    // padding slot: the last piece again
         if (j < G::PI) {
-            const int i = j * 64 + lane;                         // 16-B piece of the slab plane in LDS order
+            const int pl = j / G::PI1;                           // plane of the stage, piece inside the plane
+            const int i = (j - pl * G::PI1) * 64 + lane;         // 16-B piece of the slab plane in LDS order
             int q = i >> 1;
             if (q >= G::SPX) q = 0;                              // tail pieces land in the plane's pad
             const int ry = q / G::SW, rx = q - ry * G::SW;
             const int h2 = (i & 1) ^ ((rx >> 3) & 1);            // swizzle on bit 3 of the COLUMN
-            loff[sl] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16);
+            loff[sl] = (uint32_t)((ry * p.sWp + rx) * 32 + h2 * 16) + (uint32_t)pl * sblk;
         } else {
             loff[sl] = (uint32_t)((j - G::PI) * 1024 + lane * 16);
         }
@@ -305,7 +318,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             const int ty = trem / p.tilesX, tx = trem - ty * p.tilesX;
             pbase = p.src + (size_t)n * p.src_img + ((size_t)(ty * G::TH) * p.sWp + tx * G::TW) * 32;
         }
-        sb_i = pbase + (size_t)st_i * sblk;
+        sb_i = pbase + (size_t)st_i * PL * sblk;
         wb_i = (const char*)p.wpack + (size_t)st_i * (G::WI * 1024);
         if (++st_i == NS) {
             if (it_i + 1 < my_tiles) { st_i = 0; ++it_i; }
@@ -383,7 +396,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const int c = pcol + dx;
         bbase[dx] = (uint32_t)((wave * NP) * G::ROWB + c * 32 + 16 * (hh ^ ((c >> 3) & 1)));
     }
-    const uint32_t abase = (uint32_t)(G::PLANE + lane * 16);
+    const uint32_t abase = (uint32_t)(G::WOFF + lane * 16);
     // conv5: x of the patch's own pixels (channels 8g+4hh.. of block r) is picked out of the slab while stages 0..3 are in LDS
     const uint32_t cbase = (uint32_t)((wave * NP + 1) * G::ROWB + (pcol + 1) * 32 + 8 * hh + 16 * (((pcol + 1) >> 3) & 1));
     u32x2 hi_cap[kTrunk ? 4 : 1][kTrunk ? NP : 1][2];
@@ -525,9 +538,17 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const char* sn = smem + next_off;
         if (!PROD) cursor_next();                                 // the stage R-1 ahead: its DMA rides on this stage
 #pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {                         // the stage's planes, one after the other; the barrier sits in the last
+        const bool last = pl == PL - 1;
+        const char* sbp = sb + pl * G::PLANE;                     // this plane's slab ...
+        const uint32_t ab = abase + (uint32_t)pl * (G::WI1 * 1024);   // ... and weight block
+        // what follows this plane: the stage's next plane (already landed with it), or plane 0 of the next stage (behind the barrier)
+        const char* nbp = last ? sn : sb + (pl + 1) * G::PLANE;
+        const char* nap = last ? sn + abase : sb + ab + G::WI1 * 1024;
+#pragma unroll
         for (int t = 0; t < G::T; ++t) {
             const int dx = t / (NP + 2), s = t % (NP + 2);
-            if (t == G::T - 3) {
+            if (last && t == G::T - 3) {
                 // next stage landed + this slot released; everything below reads the NEXT slot
                 constexpr int NST = TrunkStores<EPI, CT, NP>::value;
                 // (WGL: the A fragments requested at the top of this stage are YOUNGER than the previous epilogue's stores and must
@@ -550,8 +571,8 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             // B fragment of step t+3
             {
                 const int u = t + 3;
-                if (u < G::T) breg[u % 6] = *(const f16x8*)(sb + bbase[u / (NP + 2)] + (u % (NP + 2)) * G::ROWB);
-                else breg[u % 6] = *(const f16x8*)(sn + bbase[0] + (u - G::T) * G::ROWB);
+                if (u < G::T) breg[u % 6] = *(const f16x8*)(sbp + bbase[u / (NP + 2)] + (u % (NP + 2)) * G::ROWB);
+                else breg[u % 6] = *(const f16x8*)(nbp + bbase[0] + (u - G::T) * G::ROWB);
             }
             // A fragments: the next kernel column's, one per step; behind the barrier the next stage's column 0
             if (dx < 2 && !WGL) {
@@ -560,26 +581,26 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                     const int f = s * G::AK + k;
                     if (f < 3 * CT) {
                         const int dy = f / CT, ct = f % CT;
-                        acol[dx + 1][dy][ct] = *(const f16x8*)(sb + abase + ((dy * 3 + dx + 1) * CT + ct) * 1024);
+                        acol[dx + 1][dy][ct] = *(const f16x8*)(sb + ab + ((dy * 3 + dx + 1) * CT + ct) * 1024);
                     }
                 }
             }
             if (t >= G::T - 3 && !WGL) {
                 const int dy = t - (G::T - 3);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(sn + abase + ((dy * 3) * CT + ct) * 1024);
+                for (int ct = 0; ct < CT; ++ct) acol[0][dy][ct] = *(const f16x8*)(nap + ((dy * 3) * CT + ct) * 1024);
             }
-            if constexpr (kTrunk && CAP >= 0) {
+            if constexpr (kTrunk && CAP >= 0) {                   // CAP: the x block of the stage's first plane
                 if (t >= 1 && t <= 2 * NP) {
                     const int np = (t - 1) >> 1, half = (t - 1) & 1;
-                    hi_cap[CAP][np][half] = *(const u32x2*)(sb + (cbase ^ (half * 16)) + np * G::ROWB);
+                    hi_cap[CAP + pl][np][half] = *(const u32x2*)(sbp + (cbase ^ (half * 16)) + np * G::ROWB);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
-                if ((sl * (G::T - 3)) / G::PW == t && !PROD) dma_piece(sl, dma_off);
+                if ((sl * (G::TS - 3)) / G::PW == pl * G::T + t && !PROD) dma_piece(sl, dma_off);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int np = s - dy;
@@ -588,7 +609,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 for (int ct = 0; ct < CT; ++ct) {
 #if S2SR_DIAG_NOMFMA
                     // timing diagnostic only (wrong results): the fragment reads stay alive, no MFMA is issued
-                    if (FIRST && dx == 0 && dy == 0) {
+                    if (FIRST && pl == 0 && dx == 0 && dy == 0) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) acc[ct][np][i] = 0.0f;
                     }
@@ -605,24 +626,25 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #endif
                     if (WGL) {
                         const f16x8& af = aw[WGL ? SET : 0][WGL ? (dy * 3 + dx) * CT + ct : 0];
-                        if (FIRST && dx == 0 && dy == 0) mfma_first_bias_va(acc[ct][np], af, breg[t % 6], bacc[kBiasC ? ct : 0]);
+                        if (FIRST && pl == 0 && dx == 0 && dy == 0) mfma_first_bias_va(acc[ct][np], af, breg[t % 6], bacc[kBiasC ? ct : 0]);
                         else mfma_acc_va(acc[ct][np], af, breg[t % 6]);
                         continue;
                     }
                     if (kAccV) {
-                        if (FIRST && dx == 0 && dy == 0) {
+                        if (FIRST && pl == 0 && dx == 0 && dy == 0) {
                             if (kBiasC) mfma_first_bias_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
                             else mfma_first_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                         } else mfma_acc_v(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                         continue;
                     }
-                    if (FIRST && dx == 0 && dy == 0) {
+                    if (FIRST && pl == 0 && dx == 0 && dy == 0) {
                         if (kBiasC) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc[kBiasC ? ct : 0]);
                         else mfma_first(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                     } else mfma_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (TRACE && p.trace && (p.dbg & 4) && lane == 0 && kglob == 5)
             p.trace[(size_t)blockIdx.x * 24 + 2 * 8 + wave] = __builtin_amdgcn_s_memtime();
@@ -840,12 +862,21 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     for (int it = 0; it < my_tiles; ++it) {
         const bool first_patch = it == 0;
         if (TRACE && p.trace && (p.dbg & 16) && lane == 0 && it == 2) p.trace[(size_t)blockIdx.x * 24 + 8 + wave] = __builtin_amdgcn_s_memtime();   // epilogue of patch 1 left
-        if (kTrunk) {   // NS >= 4 (host): stages 0..3 are the 64 channels of x
+        if (kTrunk && PL == 2) {   // two planes per stage: stages 0 and 1 are the 64 channels of x (NS >= 3, host)
             constexpr integral_constant<int, 0> S0{};
             stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch, S0, 0);
+            stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false, S0, 0);
+            for (int st = 2; st < NS - 1; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
+            prefetch_lo(it);
+            stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
+        } else if (kTrunk) {   // NS >= 4 (host): stages 0..3 are the 64 channels of x
+            constexpr integral_constant<int, 0> S0{};
+            stage(integral_constant<bool, true>{}, integral_constant<int, 0>{}, first_patch, S0, 0);
+            if constexpr (PL == 1) {
             stage(integral_constant<bool, false>{}, integral_constant<int, 1>{}, false, S0, 0);
             stage(integral_constant<bool, false>{}, integral_constant<int, 2>{}, false, S0, 0);
             stage(integral_constant<bool, false>{}, integral_constant<int, 3>{}, false, S0, 0);
+            }
             for (int st = 4; st < NS - 1; ++st) stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
             prefetch_lo(it);                                      // NS >= 5 (host): the last stage is peeled, the loads ride on it
             stage(integral_constant<bool, false>{}, integral_constant<int, -1>{}, false, S0, 0);
@@ -881,16 +912,17 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     }
 }
 
-template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC>
+template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC, int PL = 1>
 hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
-    using G = TG<CT, NP, R, WGL>;
+    using G = TG<CT, NP, R, WGL, PL>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::NW < 64, "vmcnt field is 6 bits");
     if (FULL == 1 && (p.mos_py != 0 || p.H % G::TH != 0 || p.W % 32 != 0)) return hipErrorInvalidValue;
     if (WGL && (p.nstage & 1)) return hipErrorInvalidValue;       // the A-fragment register sets alternate with the stage's parity
+    if (p.nstage % PL != 0) return hipErrorInvalidValue;          // whole stages of PL planes
     if (FULL == 3 && p.mos_py != 0) return hipErrorInvalidValue;
     if (FULL == 2 && (p.mos_py != 277 || p.mos_ry != 276 || p.mos_px != 277 || p.mos_rx != 276)) return hipErrorInvalidValue;
-    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL, WGL, LOE>;
+    auto kern = conv_trunk_f16<CT, NP, R, EPI, TRACE, PROD, FULL, WGL, LOE, PL>;
     static std::mutex attr_mu;
     static bool attr_set[64] = {false};
     static int ncu_dev[64] = {0};
@@ -912,7 +944,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     }
     // operand shapes the kernel's indexing assumes (a violation would read or write outside the tensors)
     if (p.nstage < 1 || p.nstage > 12 || p.sHp != p.Hp || p.sWp != p.Wp || p.Hp < p.H + 2 || p.Wp < p.W + 2) return hipErrorInvalidValue;
-    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 5 || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
+    if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.nstage < 5 * PL || !p.T || !p.xh_in || (EPI == EPI_RDB5_RRDB && (!p.xh_skip || !p.lo_skip))))
         return hipErrorInvalidValue;   // T = trunk lo out, xh_in = trunk lo in (e4m3 planes), (xh_skip, lo_skip) = the RRDB's input as an (fp16, e4m3) pair
     if ((EPI == EPI_RDB5 || EPI == EPI_RDB5_RRDB) && (p.lo_exp < 6 || p.lo_exp > 18)) return hipErrorInvalidValue;
     if (p.Hp < ((p.H + G::TH - 1) / G::TH) * G::TH + 2 || p.Wp < ((p.W + 31) / 32) * 32 + 2) return hipErrorInvalidValue;   // slabs of edge patches stay inside the plane
@@ -1622,9 +1654,16 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
 #if S2SR_EXPERIMENTAL
         if (n32 < 96 && trace) return launch_trunk_t<1, 2, 7, EPI_LRELU, true>(p, st);               // launch anatomy of the single-tile form
 #endif
-        if (n32 < 96 && !trace && !(p.f16_form & 2))
+        if (force_form == 10) return launch_trunk_t<1, 2, 3, EPI_LRELU, false, 0, 3, 0, S2SR_F16_LOENC, 2>(p, st);   // 8x32 patches, two planes per stage
+        if (n32 < 96 && !trace && !(p.f16_form & 2)) {
+#if S2SR_EXPERIMENTAL
+            if (full && (p.f16_form & 8)) return launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1, 1>(p, st);   // r04 probe: single-tile form with the weights from global memory
+#endif
+            if (S2SR_SMALL_PL == 2 && full) return launch_trunk_t<1, 2, 3, EPI_LRELU, false, 0, 1, 0, S2SR_F16_LOENC, 2>(p, st);
+            if (S2SR_SMALL_PL == 2 && plain) return launch_trunk_t<1, 2, 3, EPI_LRELU, false, 0, 3, 0, S2SR_F16_LOENC, 2>(p, st);
             return full ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st)
                         : plain ? launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 2, 7, EPI_LRELU, false>(p, st);
+        }
         if (n32 < 192 && !trace)
             return full ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st)
                         : plain ? launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 3>(p, st) : launch_trunk_t<1, 4, 5, EPI_LRELU, false>(p, st);
@@ -1656,6 +1695,9 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
 #else
         if (force_form == 2) return hipErrorNotSupported;
 #endif
+        if (force_form == 10 || (small && force_form == 0 && !trace && S2SR_SMALL_PL == 2))      // 8x32 patches, two planes per stage, double-buffered
+            return epi == EPI_RDB5 ? launch_trunk_t<2, 2, 2, EPI_RDB5, false, 0, 0, 0, S2SR_F16_LOENC, 2>(p, st)
+                                   : launch_trunk_t<2, 2, 2, EPI_RDB5_RRDB, false, 0, 0, 0, S2SR_F16_LOENC, 2>(p, st);
         if (epi == EPI_RDB5) {
 #if S2SR_EXPERIMENTAL
             if (trace) return small ? launch_trunk_t<2, 2, 5, EPI_RDB5, true>(p, st) : launch_trunk_t<2, 4, 4, EPI_RDB5, true>(p, st);

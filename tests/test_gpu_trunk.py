@@ -60,7 +60,8 @@ def _rand(rng, N, Cin, Cout, H, W):
 
 # form 1 = 16x32 patches / 5-deep ring (single tiles), form 2 = 32x32 patches / 3-deep ring (batches), form 3 = row-Winograd,
 # form 4 = form 2 with a fifth, load-only wave, form 5 = 8x32 patches / 7-deep ring (one tile on 256 CUs)
-@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
+# form 10 (r04) = 8x32 patches with TWO 16-channel planes per pipeline stage (half the barriers per patch: the single-tile form)
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 10])
 @pytest.mark.parametrize("Cin,N,H,W", [(64, 1, 16, 32), (96, 2, 33, 45), (128, 1, 65, 31), (160, 1, 7, 100), (160, 2, 40, 64)])
 def test_f16_conv14_random(eng, form, Cin, N, H, W):
     rng = np.random.default_rng(Cin * 100 + H + form)
@@ -74,7 +75,7 @@ def test_f16_conv14_random(eng, form, Cin, N, H, W):
     assert np.all(err <= tol), (float(err.max()), float(np.abs(r).max()))
 
 
-@pytest.mark.parametrize("form", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("form", [1, 2, 3, 4, 5, 10])
 def test_f16_conv14_integer_layout(eng, form):
     """Exact data: every cout reads ONE input channel through ONE tap (the channel map is a permutation with a stride, the
     tap varies with the cout), so any swapped lane / tap / channel / row shows up as a wrong integer.  LeakyReLU runs in fp32
@@ -132,7 +133,7 @@ def test_f16_conv14_whole_patch_forms(eng, form, base):
 
 # conv5 patch forms: 1 = 16x32 patches / 4-deep ring (batches), 5 = 8x32 patches / 5-deep ring (single tiles, r04: one 256x256
 # tile gives 256 patches instead of 128; its A fragments are fetched two per step)
-@pytest.mark.parametrize("form", [1, 5])
+@pytest.mark.parametrize("form", [1, 5, 10])
 @pytest.mark.parametrize("N,H,W", [(1, 16, 32), (1, 17, 70), (2, 33, 33)])
 def test_f16_conv5_random(eng, N, H, W, form):
     """conv5: v = 0.2 * (conv + b) + (x + lo), written as the (fp16 hi, e4m3(lo * 2^lo_exp)) pair; rdb3's conv5 adds
@@ -155,14 +156,14 @@ def test_f16_conv5_random(eng, N, H, W, form):
     skip = (shi.astype(np.float64) + slo).astype(np.float32)
     assert np.array_equal(skip.astype(np.float64), shi.astype(np.float64) + slo)                # exactly representable as a pair
     y2 = eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=form)
-    if form == 5:    # both patch forms accumulate in the same order: the same bytes
+    if form in (5, 10):    # every patch form accumulates in the same order: the same bytes
         assert np.array_equal(y1, eng.debug_conv_trunk(K5, x, w, b, lo=lo, form=1))
         assert np.array_equal(y2, eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=1))
     v2 = 0.2 * v1 + skip.astype(np.float64)
     assert np.all(np.abs(y2 - v2) <= bound(v2)), float(np.abs(y2 - v2).max())
 
 
-@pytest.mark.parametrize("form", [1, 5])
+@pytest.mark.parametrize("form", [1, 5, 10])
 def test_f16_conv5_integer_layout(eng, form):
     """Single-tap kernels with power-of-two data: 0.2 * acc is rounded once in fp32 (the same for oracle and kernel up to
     the fused form), so compare against the fp32 formula with 1 ulp of slack on the 0.2 product and exact channel maps."""
@@ -274,6 +275,7 @@ def test_f16_patch_forms_agree_bit_for_bit(eng):
         if native.experimental():
             assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=4)), Cin  # the loader-wave form: same stream of MFMAs
         assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=5)), Cin      # 8x32 patches
+        assert np.array_equal(y1, eng.debug_conv_trunk(K14, x, w, b, form=10)), Cin     # 8x32 patches, two planes per stage
 
 
 @pytest.mark.experimental
