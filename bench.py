@@ -229,9 +229,10 @@ PRECISION_TEXT = {
 }
 HBM_PEAK_GBS = 8000.0        # spec peak, MI355X_MICROARCH.md
 HBM_ACHIEVABLE_TBS = 6.3     # what a streaming copy achieves on this part (same guide)
-PROF_EVERY = 7               # coprime with the period of the conv1..4 (4) and conv5 / conv5-of-rdb3 (3) launch sequences; bracketing
-                             # EVERY launch puts two marker packets between all kernels and inflates a 70 us kernel's time by ~13 %
-                             # against rocprofv3's kernel duration (measured), every 7th agrees within 2 %
+PROF_EVERY = 7               # coprime with the period of the conv5 / conv5-of-rdb3 (3) launch sequence; bracketing EVERY launch puts two
+                             # marker packets between all kernels and inflates a 70 us kernel's time by ~13 % against rocprofv3's kernel
+                             # duration (measured).  conv1-4 are sampled as SPANS: one event pair around the four conv1..4 launches of
+                             # every 7th RDB (engine.hip span_begin / span_end), which spreads the pair's cost over four launches
 
 
 def roofline_block(stats: dict, precision: str, group: int, batch: int, dt_prof: float, steps: int, g0, g1) -> dict:
@@ -287,7 +288,7 @@ def roofline_block(stats: dict, precision: str, group: int, batch: int, dt_prof:
                      "hbm_ceiling_note": "arithmetic intensity x 6.3 TB/s (streaming-copy rate); with their MFMAs compiled out the trunk "
                                          "kernels run at 5.1-5.4 TB/s algorithmic (profiles/r02_trunk_anatomy.txt section 8)"},
         "stats_pass": {"every": PROF_EVERY, "ms_per_step": round(dt_prof / steps * 1e3, 3),
-                       "note": "separate pass after the timed region, direct launches + hipEvents on the launch stream"},
+                       "note": "separate pass after the timed region, direct launches + hipEvents on the launch stream; conv1-4: one event pair around the four launches of every 7th RDB"},
         "timed_pass": {"graph_replays": g1[1] - g0[1], "graph_captures_total": g1[0]},
         "families": {k: {"launches": v["launches"], "ms": round(v["total_ms"], 3),
                          "TFLOP_per_s": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 1) if v["total_ms"] else 0,
