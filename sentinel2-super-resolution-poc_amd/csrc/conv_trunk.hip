@@ -88,7 +88,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// WGL (r04 A/B; measured 3.4 % SLOWER, profiles/r04_wgl_ab.txt: experimental library only): the weights do NOT travel through the LDS-DMA ring.  Every wave fetches the 9 * CT A
+// WGL (r04 A/B; measured 3.4 % SLOWER, profiles/r04_trunk_ab.txt: experimental library only): the weights do NOT travel through the LDS-DMA ring.  Every wave fetches the 9 * CT A
 // fragments of the NEXT stage with global_load_dwordx4 straight into AGPRs (two register sets, ping-pong; the accumulators of
 // the conv1-4 forms live in architectural VGPRs, so the AGPRs are free), one stage ahead.  A stage in LDS is then the slab plane
 // alone: 20 % fewer LDS-DMA bytes and instructions, 23 % fewer LDS reads, and room for one more ring slot.
@@ -112,6 +112,9 @@ struct TG {
     static constexpr int LDS_BYTES = BIAS_OFF + CT * 128;
     static constexpr int T = 3 * (NP + 2);                     // B fragments (steps) per plane
     static constexpr int TS = PL * T;                          // ... per stage
+    // steps over which a stage's DMA instructions are spread.  Deeper rings issue them up to the barrier step (the awaited stage was
+    // issued stages ago); a DOUBLE buffer of big stages (the 64x32 form) awaits the very stage it is issuing: its pieces go out in the first third
+    static constexpr int ISS = (R_ == 2 && NP_ > 8) ? 12 : TS - 3;     // (12 steps for 20 pieces: two per step at most)
     static constexpr int PV = PW + (WGL ? WI : 0);             // vector-memory instructions per wave and stage (WGL: + the A-fragment loads)
     // ... that may stay in flight at a barrier.  WGL: the A fragments of the next stage were requested at the start of this one
     // and must have landed: only this stage's own DMA pieces, issued behind them, may still fly
@@ -120,7 +123,7 @@ struct TG {
     static_assert((NP + 2) % 2 == 0, "the 6-deep B ring needs T % 6 == 0");
     static constexpr int AK = (3 * CT + NP + 1) / (NP + 2);    // A fragments fetched per step: the 3 * CT of the next kernel column must fit the NP + 2 steps of this one
     static_assert(3 * CT <= AK * (NP + 2), "the A fragments of a kernel column must fit its steps");
-    static_assert(PW <= TS - 3, "DMA slots must fit in front of the barrier step");
+    static_assert(ISS <= TS - 3 && PW <= 2 * ISS, "DMA slots must fit in front of the barrier step");
     static_assert(PL == 1 || WGL == 0, "");
 };
 
@@ -285,6 +288,10 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 
     constexpr bool kBiasC = (EPI == EPI_LRELU) && S2SR_F16_BIASC;
     constexpr bool kAccV = (EPI == EPI_LRELU) && S2SR_F16_ACCV && !TRACE;
+    // rows whose accumulators live in architectural VGPRs (the rest in AGPRs): all of them up to 8 rows per wave; the 16-row form
+    // (64x32 patches) splits 8 + 8 -- 256 accumulator registers do not fit one file next to the fragments
+    constexpr int NPV = kAccV ? (NP > 8 ? 8 : NP) : 0;
+    constexpr bool kSplit = NPV > 0 && NPV < NP;
 
     // ---- per-lane global offsets of this wave's PW DMA pieces (patch independent)
     uint32_t loff[G::PW];
@@ -407,6 +414,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     // conv1-4: the bias rides in as the C operand of each accumulator's first MFMA (16 AGPRs per cout tile, loaded once);
     // conv5 keeps adding it in the epilogue (its AGPRs are spoken for by the residual operands)
     f32x16 bacc[kBiasC ? CT : 1];
+    f32x16 bacc_a[(kBiasC && kSplit) ? CT : 1];                  // ... and its AGPR copy for the rows that accumulate there (C and D share a file)
     if (!kEarly && kBiasC) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -470,6 +478,10 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             }
             if (kAccV) asm volatile("" : "+v"(bacc[kBiasC ? ct : 0]));
             else asm volatile("" : "+a"(bacc[kBiasC ? ct : 0]));
+            if (kSplit) {
+                bacc_a[kSplit ? ct : 0] = bacc[kBiasC ? ct : 0];
+                asm volatile("" : "+a"(bacc_a[kSplit ? ct : 0]));
+            }
         }
     }
     {
@@ -600,7 +612,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
             // LDS-DMA of the stage R-1 ahead, spread over the steps in front of the barrier
 #pragma unroll
             for (int sl = 0; sl < G::PW; ++sl)
-                if ((sl * (G::TS - 3)) / G::PW == pl * G::T + t && !PROD) dma_piece(sl, dma_off);
+                if ((sl * G::ISS) / G::PW == pl * G::T + t && !PROD) dma_piece(sl, dma_off);
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int np = s - dy;
@@ -628,6 +640,11 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                         const f16x8& af = aw[WGL ? SET : 0][WGL ? (dy * 3 + dx) * CT + ct : 0];
                         if (FIRST && pl == 0 && dx == 0 && dy == 0) mfma_first_bias_va(acc[ct][np], af, breg[t % 6], bacc[kBiasC ? ct : 0]);
                         else mfma_acc_va(acc[ct][np], af, breg[t % 6]);
+                        continue;
+                    }
+                    if (kAccV && np >= NPV) {                     // the 16-row form's upper rows: AGPR accumulators, AGPR bias
+                        if (FIRST && pl == 0 && dx == 0 && dy == 0) mfma_first_bias(acc[ct][np], acol[dx][dy][ct], breg[t % 6], bacc_a[kSplit ? ct : 0]);
+                        else mfma_acc(acc[ct][np], acol[dx][dy][ct], breg[t % 6]);
                         continue;
                     }
                     if (kAccV) {
@@ -665,7 +682,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int np = 0; np < NP; ++np) {
-                if (kAccV) asm_land_v(acc[ct][np]);
+                if (kAccV && np < NPV) asm_land_v(acc[ct][np]);
                 else asm_land(acc[ct][np]);
             }
         const int tile = it * nwg + slot_in_round;
@@ -675,6 +692,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         const int y0 = ty * G::TH, x0 = tx * G::TW;
         const int x = x0 + pcol;
         f32x16 bv[CT];
+        if constexpr (!(kBiasC && S2SR_F16_EARLYBIAS)) {          // (bias as the MFMA's C operand: nothing in LDS, the 64x32 form has no room for it)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -683,6 +701,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bv[ct][4 * g + i] = kTrunk ? v[i] * 0.2f : v[i];
             }
+        }
         const PatchLive pl = FULL ? PatchLive{0, 0, false} : patch_live(p, y0, x0);
         bool ok[NP];
         size_t opix[NP];
@@ -915,7 +934,9 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
 template <int CT, int NP, int R, int EPI, bool TRACE, int PROD = 0, int FULL = 0, int WGL = 0, int LOE = S2SR_F16_LOENC, int PL = 1>
 hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     using G = TG<CT, NP, R, WGL, PL>;
-    static_assert(G::LDS_BYTES <= 160 * 1024, "LDS ring does not fit");
+    constexpr bool kNoLdsBias = (EPI == EPI_LRELU) && S2SR_F16_BIASC && S2SR_F16_EARLYBIAS;    // bias as the C operand: no LDS copy
+    constexpr int LDSB = kNoLdsBias ? G::RING_BYTES : G::LDS_BYTES;
+    static_assert(LDSB <= 160 * 1024, "LDS ring does not fit");
     static_assert(G::NW < 64, "vmcnt field is 6 bits");
     if (FULL == 1 && (p.mos_py != 0 || p.H % G::TH != 0 || p.W % 32 != 0)) return hipErrorInvalidValue;
     if (WGL && (p.nstage & 1)) return hipErrorInvalidValue;       // the A-fragment register sets alternate with the stage's parity
@@ -933,7 +954,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     {
         std::lock_guard<std::mutex> lk(attr_mu);
         if (!attr_set[dev]) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
             if (e != hipSuccess) return e;
             int n = 256;
             (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -955,7 +976,7 @@ hipError_t launch_trunk_t(const ConvParams& p, hipStream_t st) {
     const int ntiles = q.tilesX * q.tilesY * p.N;
     int grid = ncu & ~7;
     if (ntiles < grid) grid = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PROD ? 320 : 256), G::LDS_BYTES, st, q);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PROD ? 320 : 256), LDSB, st, q);
     return hipGetLastError();
 }
 
@@ -1639,6 +1660,11 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
         if (force_form == 7) return launch_trunk_t<1, 4, 5, EPI_LRELU, false, 0, 1>(p, st);
         if (force_form == 8) return launch_trunk_t<1, 2, 7, EPI_LRELU, false, 0, 1>(p, st);
 #if S2SR_EXPERIMENTAL
+        if (force_form == 11) return launch_trunk_t<1, 16, 2, EPI_LRELU, false, 0, 1>(p, st);   // whole 64x32 patches
+#else
+        if (force_form == 11) return hipErrorNotSupported;
+#endif
+#if S2SR_EXPERIMENTAL
         if (force_form == 9) return launch_trunk_t<1, 8, 4, EPI_LRELU, false, 0, 1, 1>(p, st);   // whole 32x32 patches, weights from global memory (WGL)
 #else
         if (force_form == 9) return hipErrorNotSupported;
@@ -1672,6 +1698,9 @@ hipError_t launch_conv_trunk(const ConvParams& p, int ct, int epi, hipStream_t s
 #endif
 #if S2SR_EXPERIMENTAL
         if (full && (p.f16_form & 8)) return launch_trunk_t<1, 8, 4, EPI_LRELU, false, 0, 1, 1>(p, st);   // r04 A/B: weights from global memory, 4-deep slab ring
+#endif
+#if S2SR_EXPERIMENTAL
+        if (full && (p.f16_form & 16) && p.H % 64 == 0) return launch_trunk_t<1, 16, 2, EPI_LRELU, false, 0, 1>(p, st);   // 64x32 patches, double-buffered ring (r04 A/B: 5 % slower)
 #endif
         if (full) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 1>(p, st);
         if (plain && !(p.f16_form & 1)) return launch_trunk_t<1, 8, 3, EPI_LRELU, false, 0, 3>(p, st);

@@ -152,6 +152,7 @@ struct s2sr_handle {
     bool small8 = true;           // S2SR_SMALL8=0: single tiles keep the 16x32-patch form of fp16 conv1-4 (default: 8x32 patches, 256 per 256x256 tile)
     bool f16_loader = false;      // S2SR_F16_LOADER=1: fp16 conv1-4 (32x32-patch form) with a fifth, load-only wave (conv_trunk_f16 PROD)
     bool no_subpixel = false;     // experimental build, S2SR_NO_SUBPIXEL: up-convs in the upsample-on-load 3x3 form instead of the sub-pixel form
+    bool f16_p64 = false;         // S2SR_F16_P64=1 (r04 A/B): fp16 conv1-4 of whole-patch launches on 64x32 patches with a double-buffered ring
     bool f16_wgl = false;         // S2SR_F16_WGL=1 (r04 A/B): fp16 conv1-4 of whole-patch launches fetch their weights from global memory into AGPRs (conv_trunk_f16 WGL)
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     // paste maps of the window plan last stitched through s2sr_stitch_rows_u8_dev (row map, column map), kept on the device:
@@ -398,7 +399,7 @@ int run_conv(s2sr_handle* h, hipStream_t st, int fam, const ConvW& cw, ConvParam
         return S2SR_OK;
     }
     if (h->trunk_w4 && (fam == F_RDB14 || fam == F_RDB5) && !up && !lo_out && !cw.f8) {
-        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4) | (h->f16_wgl ? 8 : 0);
+        p.f16_form = (h->f16_loader ? 1 : 0) | (h->small8 ? 0 : 2) | (h->f16_full ? 0 : 4) | (h->f16_wgl ? 8 : 0) | (h->f16_p64 ? 16 : 0);
         const hipError_t e = launch_conv_trunk(p, cw.ct, epi, st);
         if (e == hipSuccess) return S2SR_OK;
         if (e != hipErrorNotSupported) HIPCHK(h, e);
@@ -866,6 +867,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_FP8_TAIL")) h->fp8_hp_tail = strcmp(g, "hp") == 0;
 #if S2SR_EXPERIMENTAL
     if (const char* g = getenv("S2SR_F16_WGL")) h->f16_wgl = atoi(g) != 0;
+    if (const char* g = getenv("S2SR_F16_P64")) h->f16_p64 = atoi(g) != 0;
     // kernel forms the measurements buried: only in the experimental build (s2sr_internal.h)
     if (const char* g = getenv("S2SR_TRUNK")) h->trunk_w4 = atoi(g) != 0;
     if (const char* g = getenv("S2SR_F16_LOADER")) h->f16_loader = atoi(g) != 0;

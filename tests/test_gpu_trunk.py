@@ -102,17 +102,19 @@ def test_f16_conv14_integer_layout(eng, form):
         assert np.array_equal(y, _conv64(x, w, np.zeros(32, np.float32)).astype(np.float32)), (t, form)
 
 
-@pytest.mark.parametrize("form,base", [(6, 2), (7, 1), (8, 5), (9, 2)])
+@pytest.mark.parametrize("form,base", [(6, 2), (7, 1), (8, 5), (9, 2), (11, 2)])
 def test_f16_conv14_whole_patch_forms(eng, form, base):
     """Form 9 (r04): form 6 with the weights fetched from global memory into AGPRs instead of through the LDS ring (WGL) -- the same
     MFMAs in the same order.  Forms 6 / 7 / 8: the 32x32 / 16x32 / 8x32 conv1-4 kernels compiled for launches without ragged edges or mosaic
     separators (conv_trunk_f16<..., FULL>: no px_live arithmetic, no trash-line selects in the epilogue) -- what 256x256 tile
     batches run.  Same bytes as the generic form on 32-multiple shapes, the exact-integer layout check, and a refusal
     (not a wrong answer) when the shape is ragged."""
-    if form == 9 and not native.experimental():
-        pytest.skip("weights-from-global form: experimental library only")
+    if form in (9, 11) and not native.experimental():
+        pytest.skip("weights-from-global / 64x32-patch forms: experimental library only")
     rng = np.random.default_rng(600 + form)
     for Cin, N, H, W in ((64, 1, 32, 32), (96, 2, 64, 96), (160, 1, 96, 64), (128, 3, 32, 160)):
+        if form == 11:              # 64x32 patches (16 rows per wave, accumulators split over both register files, double-buffered ring)
+            H = 64 * ((H + 63) // 64)
         x, w, b = _rand(rng, N, Cin, 32, H, W)
         y = _run14(eng, x, w, b, form)
         assert np.array_equal(y, _run14(eng, x, w, b, base)), (form, Cin, H, W)
