@@ -163,7 +163,9 @@ def cpu_baseline(seed_tiles: np.ndarray) -> dict:
             "cgroup_quota_cpus": facts["cgroup_quota_cpus"],
             "sample": f"best of {len(legs)} legs ({best_key}): {best['how']}; whole 256x256x3 tiles through the fp32 oracle (23 blocks); "
                       f"one thread does {one['GFLOP_per_s']} GFLOP/s, the best leg {best['GFLOP_per_s']} on {best['cores']} "
-                      f"(x{best['GFLOP_per_s'] / max(one['GFLOP_per_s'], 1e-9):.1f} of one thread)",
+                      f"(x{best['GFLOP_per_s'] / max(one['GFLOP_per_s'], 1e-9):.1f} of one thread)"
+                      + (f"; this process may use {facts['cgroup_quota_cpus']:g} CPUs (cgroup cpu.max) of the host's {facts['physical']} physical cores, "
+                         f"and batch-1 fp32 convs of this size stop scaling near 16 oneDNN threads (profiles/r04_cpu_probe.txt)" if facts["cgroup_quota_cpus"] else ""),
             "s_per_tile": best["s_per_tile"], "GFLOP_per_s": best["GFLOP_per_s"], "one_thread": one, "legs": legs}
 
 
