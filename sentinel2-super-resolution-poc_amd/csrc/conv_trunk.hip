@@ -565,7 +565,10 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 constexpr int NST = TrunkStores<EPI, CT, NP>::value;
                 // (WGL: the A fragments requested at the top of this stage are YOUNGER than the previous epilogue's stores and must
                 // have landed: no allowance for the stores)
-                constexpr int NEPI = WGL ? G::NW : ((G::NW + NST < 63) ? G::NW + NST : 63);
+                // (R == 2, a double buffer: the awaited stage's DMA pieces are issued in THIS stage, behind the previous epilogue's
+                // stores -- an allowance for the stores would leave that many of the awaited pieces in flight: r04, found by
+                // test_window_mosaics_give_the_same_bytes on the two-plane conv5 form with several patches per workgroup)
+                constexpr int NEPI = (WGL || R == 2) ? G::NW : ((G::NW + NST < 63) ? G::NW + NST : 63);
                 if (PROD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // my only vector-memory traffic are stores
                 else if (FIRST && !first_patch) wait_release_barrier<NEPI>();
                 else wait_release_barrier<G::NW>();

@@ -298,3 +298,21 @@ def test_f16_conv5_lo_encoding_forms_agree(eng):
             a = eng.debug_conv_trunk(kind, x, w, b, lo=lo, form=1, **kw)
             c = eng.debug_conv_trunk(kind, x, w, b, lo=lo, form=2, **kw)
             assert np.array_equal(a, c), (scale, kind, float(np.abs(a - c).max()))
+
+
+@pytest.mark.parametrize("form", [5, 10])
+def test_f16_small_forms_with_several_patches_per_workgroup(eng, form):
+    """The single-tile forms (8x32 patches; form 10: two planes per stage, conv5 on a double-buffered ring) on launches with MORE
+    patches than workgroups -- 432 patches on 256 workgroups: the patch boundary inside a workgroup (the first stage of a second
+    patch waits behind the previous epilogue's stores) is a path the single-patch shapes above never take.  r04: the double
+    buffer's wait allowed the epilogue's stores to stand in for the awaited stage's DMA pieces.  Same bytes as the 16x32 forms."""
+    rng = np.random.default_rng(900 + form)
+    N, H, W = 6, 96, 192
+    x, w, b = _rand(rng, N, 160, 32, H, W)
+    assert np.array_equal(eng.debug_conv_trunk(K14, x, w, b, form=form), eng.debug_conv_trunk(K14, x, w, b, form=1))
+    x, w, b = _rand(rng, N, 192, 64, H, W)
+    le = eng.debug_config()["lo_exp"]
+    lo = (rng.integers(-7, 8, size=(N, 64, H, W)) * 2.0 ** (-4 - le)).astype(np.float32)
+    skip = _h(rng.standard_normal((N, 64, H, W)).astype(np.float32))
+    assert np.array_equal(eng.debug_conv_trunk(K5, x, w, b, lo=lo, form=form), eng.debug_conv_trunk(K5, x, w, b, lo=lo, form=1))
+    assert np.array_equal(eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=form), eng.debug_conv_trunk(K5R, x, w, b, lo=lo, skip=skip, form=1))
