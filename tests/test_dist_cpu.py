@@ -108,7 +108,7 @@ def _worker(rank, world, port, cases, q):
     g0 = sd.enhance_distributed(be, img, tile, pad, stats=st)        # the default: gather to rank 0, the job's one consumer
     assert (g0 is None) == (rank != 0)
     # several chunks per rank, and (on the consumer) the image went out band by band, one band per distinct window row
-    assert len(st["chunks"]) >= 2 and sum(st["chunks"]) == st["per_rank"], st
+    assert (len(st["chunks"]) >= 2 or st["per_rank"] == 1) and sum(st["chunks"]) == st["per_rank"], st
     if rank == 0:
         assert st["bands"] >= 2 and be.calls["stitch_rows"] - n_rows == st["bands"], (st, be.calls)
     if rank == 0:
@@ -160,7 +160,7 @@ def _expected():
     return exp
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])       # 8: the node the driver scales to (more ranks than windows in two of the cases)
 def test_rank_count_invariance(world):
     res, ok_blob = _run(world)
     exp = _expected()
