@@ -31,22 +31,34 @@ logger = logging.getLogger("tiling")
 _PNG_SIG = b"\x89PNG\r\n\x1a\n"
 
 
-def encode_png_rgba(tile: np.ndarray, level: int = 3) -> bytes:
-    """256x256x4 uint8 -> PNG bytes (8-bit RGBA, Sub filter on every row, one IDAT).  Plain zlib calls,
-    which release the GIL: tiles are encoded on a thread pool (gdal2tiles uses --processes 4 for this)."""
-    h, w, _ = tile.shape
-    rows = tile.reshape(h, w * 4)
-    sub = rows.copy()
-    sub[:, 4:] = rows[:, 4:] - rows[:, :-4]                    # PNG filter type 1, bpp = 4 (wraps modulo 256)
-    raw = np.empty((h, w * 4 + 1), np.uint8)
-    raw[:, 0] = 1
-    raw[:, 1:] = sub
+def filter_sub_rgba(tiles_arr: np.ndarray) -> np.ndarray:
+    """[..., 256, 256, 4] uint8 -> [..., 256, 1 + 1024]: every row behind its PNG filter byte (type 1, Sub, bpp = 4; wraps modulo
+    256).  One vectorised pass over a whole zoom level: per tile this is interpreter overhead, per level it is memory bandwidth."""
+    lead, (h, w, _) = tiles_arr.shape[:-3], tiles_arr.shape[-3:]
+    rows = tiles_arr.reshape(lead + (h, w * 4))
+    raw = np.empty(lead + (h, w * 4 + 1), np.uint8)
+    raw[..., 0] = 1
+    raw[..., 1:5] = rows[..., :4]
+    np.subtract(rows[..., 4:], rows[..., :-4], out=raw[..., 5:])
+    return raw
+
+
+def _png_from_filtered(raw: np.ndarray, level: int, strategy: int) -> bytes:
+    h, w = raw.shape[0], (raw.shape[1] - 1) // 4
 
     def chunk(kind: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, strategy)
     return (_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) +
-            chunk(b"IDAT", zlib.compress(raw.tobytes(), level)) + chunk(b"IEND", b""))
+            chunk(b"IDAT", co.compress(raw.tobytes()) + co.flush()) + chunk(b"IEND", b""))
+
+
+def encode_png_rgba(tile: np.ndarray, level: int = 1, strategy: int = zlib.Z_RLE) -> bytes:
+    """256x256x4 uint8 -> PNG bytes (8-bit RGBA, Sub filter on every row, one IDAT).  Plain zlib calls,
+    which release the GIL: tiles are encoded on a thread pool (gdal2tiles uses --processes 4 for this).  Level 1 + Z_RLE
+    (the fast end of deflate, what cv2.imwrite defaults to): r03's level 3 spent 2 s of a z10-18 pyramid in deflate."""
+    return _png_from_filtered(filter_sub_rgba(tile), level, strategy)
 
 _ENGINE: Optional[native.Engine] = None
 
@@ -130,8 +142,8 @@ def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_z
     levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
 
     def write_tile(args):
-        t, path = args
-        path.write_bytes(encode_png_rgba(t))
+        raw, path = args
+        path.write_bytes(_png_from_filtered(raw, 1, zlib.Z_RLE))
 
     prev, prev_lv = None, None
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
@@ -146,7 +158,8 @@ def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_z
             for i in range(lv.nx):
                 if has_data[:, i].any():
                     (output_dir / str(lv.zoom) / str(lv.tminx + i)).mkdir(parents=True, exist_ok=True)
-            jobs = [(cur[j, i], output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png")
+            filt = filter_sub_rgba(cur)                                 # the PNG row filter for the whole level in one pass
+            jobs = [(filt[j, i], output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png")
                     for j, i in zip(*np.nonzero(has_data))]
             pending.append(pool.map(write_tile, jobs, chunksize=8))     # encoded while the next level is computed
             prev, prev_lv = cur, lv

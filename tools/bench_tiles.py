@@ -57,4 +57,4 @@ opx = plan.out_h * plan.out_w
 print(f"source {side}x{side} -> EPSG:3857 {plan.out_w}x{plan.out_h}; plan {t_plan*1e3:.1f} ms")
 print(f"warp: call {t_warp*1e3:.1f} ms (kernel {k_warp:.3f} ms = {opx*(4+12)/k_warp/1e6:.0f} GB/s at 16 B per output px)")
 print(f"pyramid z18..10: {ntiles} tiles, calls {t_tiles*1e3:.1f} ms (kernels {k_tiles:.3f} ms)")
-print(f"PNG encode on the host (zlib level 3, {nthr} threads): {nenc} tiles, {total_bytes/1e6:.0f} MB in {t_png*1e3:.0f} ms")
+print(f"PNG encode on the host (zlib level 1 + Z_RLE, {nthr} threads): {nenc} tiles, {total_bytes/1e6:.0f} MB in {t_png*1e3:.0f} ms")
