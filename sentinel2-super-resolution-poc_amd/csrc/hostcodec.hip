@@ -7,7 +7,7 @@
 #include "../../include/s2sr.h"
 
 extern "C" int s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
-    if (!src || !dst || !out_n) return S2SR_E_INVALID;
+    if ((!src && n) || !dst || !out_n) return S2SR_E_INVALID;
     // TIFF 6.0 section 13: MSB-first codes of 9..12 bits, ClearCode 256, EndOfInformation 257, code
     // width grows one code early ("early change")
     static const int MAXC = 4096;
@@ -71,7 +71,7 @@ extern "C" int s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, 
 // Worst case output is ~1.4x the input (12-bit codes for single bytes) + a few bytes: the caller
 // sizes dst as n*3/2 + 16.
 extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
-    if (!src || !dst || !out_n) return S2SR_E_INVALID;
+    if ((!src && n) || !dst || !out_n) return S2SR_E_INVALID;
     static const int HBITS = 14, HSIZE = 1 << HBITS;   // 4x the 4096 codes; entries carry a generation stamp
     uint32_t hkey[HSIZE];                                // so a ClearCode does not cost a table wipe
     uint16_t hval[HSIZE];

@@ -8,9 +8,15 @@ Supports: little/big endian, classic TIFF and BigTIFF, strips or tiles, PlanarCo
 float64 samples of 8/16/32/64 bits.  Returns the first image of the file as [H, W, bands] plus
 the raw tag dictionary (GeoTIFF tags included).  LZW strips are decoded by the native library
 (host code, s2sr_tiff_lzw_decode); everything else is numpy + zlib.
+
+Uploaded files reach this reader (app/sr_routes.py /api/enhance), so a malformed file is a TiffError whatever it breaks
+(offsets past the end, zero or absurd dimensions, missing tags, corrupt streams), a Deflate chunk is inflated to the size its
+geometry says and no further, and an image above S2SR_TIFF_MAX_BYTES decoded bytes (default 4 GiB) is refused before anything
+is allocated.  tests/test_tiff_cpu.py mutates valid files at random to hold that line.
 """
 from __future__ import annotations
 
+import os
 import struct
 import zlib
 from pathlib import Path
@@ -90,7 +96,7 @@ def _decompress(comp: int, data: bytes, expected: int) -> bytes:
     if comp == 1:
         return data
     if comp in (8, 32946):
-        return zlib.decompress(data)
+        return zlib.decompressobj().decompress(data, expected)      # a chunk never needs more than its geometry: no inflate bombs
     if comp == 5:
         return _lzw(data, expected)
     if comp == 32773:
@@ -105,8 +111,22 @@ def _dtype(bits: int, fmt: int, bo: str) -> np.dtype:
     return np.dtype(f"{'<' if bo == '<' else '>'}{kind}{bits // 8}")
 
 
+def max_decoded_bytes() -> int:
+    return int(os.environ.get("S2SR_TIFF_MAX_BYTES", str(1 << 32)))
+
+
 def read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
-    """-> (array [H, W, bands] in native byte order, {tag: values})."""
+    """-> (array [H, W, bands] in native byte order, {tag: values}).  TiffError for anything it cannot or will not decode."""
+    try:
+        return _read_tiff(path)
+    except TiffError:
+        raise
+    except (struct.error, KeyError, IndexError, ZeroDivisionError, OverflowError, zlib.error, MemoryError, ValueError,
+            RuntimeError) as e:      # RuntimeError: the native LZW decoder's S2srError on a corrupt stream
+        raise TiffError(f"{path}: malformed TIFF ({type(e).__name__}: {e})") from e
+
+
+def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
     raw = Path(path).read_bytes()
     buf = memoryview(raw)
     if len(raw) < 8 or raw[:2] not in (b"II", b"MM"):
@@ -145,17 +165,24 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
         cw, ch = W, int(t.get(ROWS_PER_STRIP, (H,))[0])
         ch = min(ch, H) if ch > 0 else H
         offs, cnts = t[STRIP_OFFSETS], t[STRIP_BYTE_COUNTS]
+    if min(W, H, spp, cw, ch) <= 0 or planar not in (1, 2):
+        raise TiffError(f"{path}: {W}x{H}x{spp}, chunks {cw}x{ch}, PlanarConfiguration {planar}")
     nx, ny = (W + cw - 1) // cw, (H + ch - 1) // ch
+    cap = max_decoded_bytes()
+    if H * W * spp * dt.itemsize > cap or nx * ny * cw * ch * spp * dt.itemsize > 4 * cap:
+        raise TiffError(f"{path}: {W}x{H}x{spp} {dt} in {cw}x{ch} chunks is above S2SR_TIFF_MAX_BYTES = {cap}")
     planes = spp if planar == 2 else 1
     cspp = 1 if planar == 2 else spp          # samples per pixel inside one chunk
-    if len(offs) < nx * ny * planes:
-        raise TiffError(f"{path}: {len(offs)} chunks listed, {nx * ny * planes} needed")
+    if len(offs) < nx * ny * planes or len(cnts) < nx * ny * planes:
+        raise TiffError(f"{path}: {len(offs)} chunk offsets and {len(cnts)} byte counts listed, {nx * ny * planes} needed")
     out = np.zeros((H, W, spp), dtype=dt.newbyteorder("="))
 
     def chunk(k: int) -> None:          # chunks are independent: decoded on a thread pool (zlib and the
         pl, rem = divmod(k, nx * ny)    # native LZW decoder both run without the GIL)
         iy, ix = divmod(rem, nx)
         o, c = int(offs[k]), int(cnts[k])
+        if o + c > len(raw):
+            raise TiffError(f"{path}: chunk {k} ({c} bytes at {o}) runs past the end of the file")
         rows = ch if tiled else min(ch, H - iy * ch)    # strips are not padded, tiles are
         expected = rows * cw * cspp * dt.itemsize
         data = _decompress(comp, bytes(buf[o:o + c]), expected)
