@@ -15,6 +15,11 @@
 
 using namespace s2sr;
 
+std::recursive_mutex& s2sr::device_gate() {      // see s2sr_internal.h
+    static std::recursive_mutex m;
+    return m;
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -204,13 +209,13 @@ std::vector<ConvSpec> conv_specs(int num_block) {
 
 void free_weights(s2sr_handle* h) {
     for (ConvW& c : h->convs) {
-        if (!c.pooled && c.d_wpack) hipFree(c.d_wpack);
+        if (!c.pooled && c.d_wpack) dev_free(c.d_wpack);
         for (int k = 0; k < 2; ++k)
-            if (c.d_wphase[k]) hipFree(c.d_wphase[k]);
+            if (c.d_wphase[k]) dev_free(c.d_wphase[k]);
     }
-    if (h->pool_w) hipFree(h->pool_w);
-    if (h->pool_s) hipFree(h->pool_s);
-    if (h->pool_b) hipFree(h->pool_b);
+    if (h->pool_w) dev_free(h->pool_w);
+    if (h->pool_s) dev_free(h->pool_s);
+    if (h->pool_b) dev_free(h->pool_b);
     h->pool_w = nullptr; h->pool_s = nullptr; h->pool_b = nullptr;
     h->convs.clear();
 }
@@ -226,16 +231,28 @@ int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
     if (h->d_scratch[slot]) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         drop_graphs(h);
-        HIPCHK(h, hipFree(h->d_scratch[slot]));
+        HIPCHK(h, dev_free(h->d_scratch[slot]));
         h->d_scratch[slot] = nullptr;
         h->scratch_bytes[slot] = 0;
     }
-    HIPCHK(h, hipMalloc(&h->d_scratch[slot], bytes));
+    HIPCHK(h, dev_malloc(&h->d_scratch[slot], bytes));
     h->scratch_bytes[slot] = bytes;
     return S2SR_OK;
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Blocking copies / fills go through one of the handle's own (non-blocking) streams, never the legacy stream: the runtime refuses
+// any legacy-stream operation (hipMemcpy, hipMemset) while ANY stream of the process captures a graph, and it also invalidates
+// that capture -- two handles on two threads (the x4 and the anime engine under Starlette's pool) hit exactly that in the r04 soak.
+hipError_t copy_blocking(s2sr_handle* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+}
+hipError_t fill_blocking(s2sr_handle* h, void* dst, int value, size_t bytes) {
+    hipError_t e = hipMemsetAsync(dst, value, bytes, h->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+}
 
 int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mos_px = 0) {
     Workspace& w = h->ws;
@@ -245,9 +262,9 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mo
     // were written as plain images (or as a mosaic of another period) are not reused
     if (w.base && w.G >= G && w.H == H && w.W == W && w.hp == hp && w.fp8 == fp8 && w.mos_py == mos_py && w.mos_px == mos_px) return S2SR_OK;
     if (w.base) {
-        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, dev_sync());
         drop_graphs(h);
-        HIPCHK(h, hipFree(w.base));
+        HIPCHK(h, dev_free(w.base));
         w = Workspace();
     }
     w.G = G; w.H = H; w.W = W; w.hp = hp; w.fp8 = fp8; w.mos_py = mos_py; w.mos_px = mos_px;
@@ -278,7 +295,7 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mo
     }
     w.bytes = off;
     {
-        const hipError_t em = hipMalloc((void**)&w.base, w.bytes);
+        const hipError_t em = dev_malloc(&w.base, w.bytes);
         if (em != hipSuccess) {                       // leave a clean "no workspace" state: the caller may retry with a smaller group
             (void)hipGetLastError();
             w = Workspace();
@@ -287,9 +304,8 @@ int ensure_workspace(s2sr_handle* h, int G, int H, int W, int mos_py = 0, int mo
             return fail(h, em == hipErrorOutOfMemory ? S2SR_E_CAPACITY : S2SR_E_HIP, b);
         }
     }
-    HIPCHK(h, hipMemset(w.base, 0, w.bytes));   // the zero halos
+    HIPCHK(h, fill_blocking(h, w.base, 0, w.bytes));   // the zero halos
     ++h->ws_allocs;
-    HIPCHK(h, hipDeviceSynchronize());
     w.P0 = w.base + oP0; w.D[0] = w.base + oD0; w.D[1] = w.base + oD1; w.D[2] = w.base + oD2; w.U0 = w.base + oU0;
     w.T = w.base + oT; w.Tr[0] = w.base + oT0; w.Tr[1] = w.base + oT1; w.Tr[2] = w.base + oT2; w.R = (float*)(w.base + oR); w.F = (float*)(w.base + oF);
     w.U1 = w.base + oU1; w.U2 = w.base + oU2; w.U3 = w.base + oU3;
@@ -353,7 +369,7 @@ void span_end(s2sr_handle* h, hipStream_t st) {
 
 int collect_events(s2sr_handle* h) {
     if (h->evs.empty()) return S2SR_OK;
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, dev_sync());
     for (EvRec& r : h->evs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -755,6 +771,7 @@ int forward_dev(s2sr_handle* h, hipStream_t st, const uint8_t* d_tiles, const fl
                 ge = nullptr;
             } else if (!ge->exec && !ge->refused) {   // second sighting: capture
                 hipGraph_t graph = nullptr;
+                DeviceGate gate;     // no device-wide call of any handle while this one captures (s2sr_internal.h)
                 bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
                     const int erc = enqueue();
@@ -885,7 +902,7 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
     if (const char* g = getenv("S2SR_FP8_XEXP")) h->fp8_x_exp = atoi(g);
     if (const char* g = getenv("S2SR_FP8_GEXP")) h->fp8_g_exp = atoi(g);
     h->fp8_x_exp0 = h->fp8_x_exp; h->fp8_g_exp0 = h->fp8_g_exp;
-    if (hipMalloc((void**)&h->d_trash, 8192) != hipSuccess) {
+    if (dev_malloc(&h->d_trash, 8192) != hipSuccess) {
         hipStreamDestroy(h->copy_stream);
         hipStreamDestroy(h->stream);
         delete h;
@@ -902,21 +919,21 @@ int s2sr_create(const s2sr_config* cfg, s2sr_handle** out) {
 void s2sr_destroy(s2sr_handle* h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
-    hipDeviceSynchronize();
+    dev_sync();
     drop_graphs(h);
     free_weights(h);
-    if (h->ws.base) hipFree(h->ws.base);
-    if (h->d_trash) hipFree(h->d_trash);
+    if (h->ws.base) dev_free(h->ws.base);
+    if (h->d_trash) dev_free(h->d_trash);
     for (int i = 0; i < 6; ++i)
-        if (h->d_scratch[i]) hipFree(h->d_scratch[i]);
+        if (h->d_scratch[i]) dev_free(h->d_scratch[i]);
     for (EvRec& r : h->evs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : h->group_done) hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
-        if (h->stage_buf[i]) hipHostFree(h->stage_buf[i]);
+        if (h->stage_buf[i]) host_free(h->stage_buf[i]);
         if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
     }
-    if (h->d_stitch_maps) hipFree(h->d_stitch_maps);
+    if (h->d_stitch_maps) dev_free(h->d_stitch_maps);
     if (h->host_copy_ev) hipEventDestroy(h->host_copy_ev);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -934,7 +951,7 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
         snprintf(b, sizeof b, "weight blob has %zu floats, a %d-block net needs %zu", n_floats, h->cfg.num_block, want);
         return fail(h, S2SR_E_BADBLOB, b);
     }
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, dev_sync());
     drop_graphs(h);
     free_weights(h);
     h->has_weights = false;
@@ -958,19 +975,19 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
                                        : wino ? conv_wpack_bytes_wino(specs[i].cin, specs[i].cout) : conv_wpack_bytes(specs[i].cin, specs[i].cout));
         }
     }
-    HIPCHK(h, hipMalloc((void**)&h->pool_w, pool_bytes ? pool_bytes : 256));
-    HIPCHK(h, hipMalloc((void**)&h->pool_b, nconv * 64 * sizeof(float)));
-    if (fp8) HIPCHK(h, hipMalloc((void**)&h->pool_s, nconv * 64 * sizeof(int32_t)));
+    HIPCHK(h, dev_malloc(&h->pool_w, pool_bytes ? pool_bytes : 256));
+    HIPCHK(h, dev_malloc(&h->pool_b, nconv * 64 * sizeof(float)));
+    if (fp8) HIPCHK(h, dev_malloc(&h->pool_s, nconv * 64 * sizeof(int32_t)));
     {   // biases: one gather kernel
         uint64_t* d_off = nullptr;
         int32_t* d_cout = nullptr;
-        HIPCHK(h, hipMalloc((void**)&d_off, nconv * 8));
-        HIPCHK(h, hipMalloc((void**)&d_cout, nconv * 4));
+        HIPCHK(h, dev_malloc(&d_off, nconv * 8));
+        HIPCHK(h, dev_malloc(&d_cout, nconv * 4));
         HIPCHK(h, hipMemcpyAsync(d_off, boff.data(), nconv * 8, hipMemcpyHostToDevice, st));
         HIPCHK(h, hipMemcpyAsync(d_cout, couts.data(), nconv * 4, hipMemcpyHostToDevice, st));
         HIPCHK(h, launch_gather_bias(d_blob, d_off, d_cout, (int)nconv, h->pool_b, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        hipFree(d_off); hipFree(d_cout);
+        dev_free(d_off); dev_free(d_cout);
     }
     std::vector<char> tmp;
     std::vector<float> hw;
@@ -1028,12 +1045,12 @@ static int load_weights_locked(s2sr_handle* h, const float* d_blob, size_t n_flo
                 std::vector<char> ph(pb);
                 for (int k = 0; k < 2; ++k) {
                     pack_conv_weights_phase_f8hp(pw, s.cin, s.cout, k, ph.data());
-                    HIPCHK(h, hipMalloc(&cw.d_wphase[k], pb));
-                    HIPCHK(h, hipMemcpy(cw.d_wphase[k], ph.data(), pb, hipMemcpyHostToDevice));
+                    HIPCHK(h, dev_malloc(&cw.d_wphase[k], pb));
+                    HIPCHK(h, copy_blocking(h, cw.d_wphase[k], ph.data(), pb, hipMemcpyHostToDevice));
                 }
             }
-            HIPCHK(h, hipMalloc(&cw.d_wpack, wb));
-            HIPCHK(h, hipMemcpy(cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
+            HIPCHK(h, dev_malloc(&cw.d_wpack, wb));
+            HIPCHK(h, copy_blocking(h, cw.d_wpack, tmp.data(), wb, hipMemcpyHostToDevice));
         }
         h->convs.push_back(cw);
     }
@@ -1048,15 +1065,15 @@ int s2sr_load_weights(s2sr_handle* h, const float* blob, size_t n_floats) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (n_floats != s2sr_expected_blob_floats(h->cfg.num_block)) return load_weights_locked(h, nullptr, n_floats, h->stream);   // -> BADBLOB text
     float* d_blob = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_blob, n_floats * sizeof(float)));
+    HIPCHK(h, dev_malloc(&d_blob, n_floats * sizeof(float)));
     hipError_t e = hipMemcpyAsync(d_blob, blob, n_floats * sizeof(float), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
-        hipFree(d_blob);
+        dev_free(d_blob);
         return fail(h, S2SR_E_HIP, std::string("upload of the weight blob failed: ") + hipGetErrorString(e));
     }
     const int rc = load_weights_locked(h, d_blob, n_floats, h->stream);
-    hipFree(d_blob);
+    dev_free(d_blob);
     return rc;
 }
 
@@ -1148,7 +1165,7 @@ static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t b
         return S2SR_OK;
     }
     for (int i = 0; i < 2; ++i) {
-        if (!h->stage_buf[i]) HIPCHK(h, hipHostMalloc(&h->stage_buf[i], kStageBytes, hipHostMallocDefault));
+        if (!h->stage_buf[i]) HIPCHK(h, host_malloc(&h->stage_buf[i], kStageBytes, hipHostMallocDefault));
         if (!h->stage_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     }
     const size_t nsl = (bytes + kStageBytes - 1) / kStageBytes;
@@ -1170,7 +1187,7 @@ static int d2h_staged(s2sr_handle* h, uint8_t* dst, const uint8_t* src, size_t b
 int s2sr_host_alloc(size_t bytes, void** out) {
     if (!out || bytes == 0) return S2SR_E_INVALID;
     *out = nullptr;
-    if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) {
+    if (host_malloc(out, bytes, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         *out = nullptr;
         return S2SR_E_HIP;
@@ -1180,7 +1197,7 @@ int s2sr_host_alloc(size_t bytes, void** out) {
 
 int s2sr_host_free(void* p) {
     if (!p) return S2SR_OK;
-    if (hipHostFree(p) != hipSuccess) {
+    if (host_free(p) != hipSuccess) {
         (void)hipGetLastError();
         return S2SR_E_HIP;
     }
@@ -1567,16 +1584,16 @@ int s2sr_stitch_rows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int3
         std::vector<int32_t> rm, cm;
         build_stitch_maps(wins, nx, ny, 4 * H, 4 * W, rm, cm);
         if (h->stitch_maps_cap < (nrm + ncm) * 4) {
-            HIPCHK(h, hipDeviceSynchronize());     // a stitch of the previous plan may still read the old maps
-            if (h->d_stitch_maps) HIPCHK(h, hipFree(h->d_stitch_maps));
+            HIPCHK(h, dev_sync());     // a stitch of the previous plan may still read the old maps
+            if (h->d_stitch_maps) HIPCHK(h, dev_free(h->d_stitch_maps));
             h->d_stitch_maps = nullptr; h->stitch_maps_cap = 0; h->stitch_key[0] = 0;
-            HIPCHK(h, hipMalloc((void**)&h->d_stitch_maps, (nrm + ncm) * 4));
+            HIPCHK(h, dev_malloc(&h->d_stitch_maps, (nrm + ncm) * 4));
             h->stitch_maps_cap = (nrm + ncm) * 4;
         } else {
-            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, dev_sync());
         }
-        HIPCHK(h, hipMemcpy(h->d_stitch_maps, rm.data(), nrm * 4, hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(h->d_stitch_maps + nrm, cm.data(), ncm * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_blocking(h, h->d_stitch_maps, rm.data(), nrm * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_blocking(h, h->d_stitch_maps + nrm, cm.data(), ncm * 4, hipMemcpyHostToDevice));
         h->stitch_key[0] = H; h->stitch_key[1] = W; h->stitch_key[2] = tile; h->stitch_key[3] = pad + 1;
     }
     const int32_t* d_rm = h->d_stitch_maps;
@@ -1766,7 +1783,7 @@ int s2sr_synchronize(s2sr_handle* h) {
     if (!h) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, dev_sync());
     return S2SR_OK;
 }
 
@@ -1784,7 +1801,7 @@ int s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t 
     if (rc) return rc;
     if ((rc = ensure_scratch(h, 1, ob))) return rc;
     float* d_c = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_c, 2 * sizeof(float)));
+    HIPCHK(h, dev_malloc(&d_c, 2 * sizeof(float)));
     HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], tiles, ib, hipMemcpyHostToDevice, h->stream));
     const int old_x = h->fp8_x_exp, old_g = h->fp8_g_exp, old_prof = h->prof;
     const bool old_graphs = h->graphs_on;
@@ -1797,7 +1814,7 @@ int s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t 
     bool clipped = false;
     for (int attempt = 0; attempt < 3; ++attempt) {
         hipError_t e0 = hipMemsetAsync(d_c, 0, 2 * sizeof(float), h->stream);
-        if (e0 != hipSuccess) { hipFree(d_c); return fail(h, S2SR_E_HIP, "calibration memset failed"); }
+        if (e0 != hipSuccess) { dev_free(d_c); return fail(h, S2SR_E_HIP, "calibration memset failed"); }
         h->fp8_x_exp = mx; h->fp8_g_exp = mg;
         h->graphs_on = false; h->prof = 0;
         h->d_calib = d_c;
@@ -1813,7 +1830,7 @@ int s2sr_calibrate_fp8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t 
         if (cx) mx -= 3;
         if (cg) mg -= 3;
     }
-    hipFree(d_c);
+    dev_free(d_c);
     if (rc || e != hipSuccess) {
         h->fp8_x_exp = old_x; h->fp8_g_exp = old_g;
         return rc ? rc : fail(h, S2SR_E_HIP, std::string("calibration read-back failed: ") + hipGetErrorString(e));
@@ -1866,11 +1883,11 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
                  yb = (size_t)N * Cout * OHh * OWw * 4, wb = conv_wpack_bytes(Cin, Cout);
     char *d_plane = nullptr, *d_w = nullptr;
     float *d_x = nullptr, *d_y = nullptr, *d_b = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_plane, plane_b));
-    HIPCHK(h, hipMalloc((void**)&d_x, xb));
-    HIPCHK(h, hipMalloc((void**)&d_y, yb));
-    HIPCHK(h, hipMalloc((void**)&d_w, wb));
-    HIPCHK(h, hipMalloc((void**)&d_b, 64 * 4));
+    HIPCHK(h, dev_malloc(&d_plane, plane_b));
+    HIPCHK(h, dev_malloc(&d_x, xb));
+    HIPCHK(h, dev_malloc(&d_y, yb));
+    HIPCHK(h, dev_malloc(&d_w, wb));
+    HIPCHK(h, dev_malloc(&d_b, 64 * 4));
     std::vector<char> wp(wb);
     pack_conv_weights(weight, Cin, Cout, 1, wp.data());
     float bb[64] = {0};
@@ -1887,7 +1904,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, launch_conv(p, (Cout + 31) / 32, EPI_DEBUG, upsample != 0, false, st));
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    hipFree(d_plane); hipFree(d_x); hipFree(d_y); hipFree(d_w); hipFree(d_b);
+    dev_free(d_plane); dev_free(d_x); dev_free(d_y); dev_free(d_w); dev_free(d_b);
     return S2SR_OK;
 }
 
@@ -1912,7 +1929,7 @@ float e4m3_to_f32(uint8_t b) {   // OCP e4m3fn: bias 7, subnormals, 0x7f / 0xff 
 typedef _Float16 hf16;
 struct DevBuf {   // frees on scope exit: the hook has many early returns
     void* p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) dev_free(p); }
 };
 }  // namespace
 
@@ -1935,12 +1952,12 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
     // ---- weights through the production device packers
     DevBuf d_w32, d_wp, d_b, d_ws;
     const size_t wn = (size_t)Cout * Cin * 9;
-    HIPCHK(h, hipMalloc(&d_w32.p, wn * 4));
+    HIPCHK(h, dev_malloc(&d_w32.p, wn * 4));
     HIPCHK(h, hipMemcpyAsync(d_w32.p, a->weight, wn * 4, hipMemcpyHostToDevice, st));
     const bool wino = kind == 0 && a->form == 3;
-    HIPCHK(h, hipMalloc(&d_wp.p, f8 ? conv_wpack_bytes_f8(Cin, Cout) : wino ? conv_wpack_bytes_wino(Cin, Cout) : conv_wpack_bytes(Cin, Cout)));
-    HIPCHK(h, hipMalloc(&d_b.p, 64 * 4));
-    HIPCHK(h, hipMalloc(&d_ws.p, 64 * 4));
+    HIPCHK(h, dev_malloc(&d_wp.p, f8 ? conv_wpack_bytes_f8(Cin, Cout) : wino ? conv_wpack_bytes_wino(Cin, Cout) : conv_wpack_bytes(Cin, Cout)));
+    HIPCHK(h, dev_malloc(&d_b.p, 64 * 4));
+    HIPCHK(h, dev_malloc(&d_ws.p, 64 * 4));
     float bb[64] = {0};
     memcpy(bb, a->bias, Cout * sizeof(float));
     HIPCHK(h, hipMemcpyAsync(d_b.p, bb, sizeof bb, hipMemcpyHostToDevice, st));
@@ -1979,7 +1996,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
                     }
     };
     DevBuf d_D, d_D2, d_Tin, d_Tout, d_Sk, d_SkLo, d_Xin, d_Xout;
-    HIPCHK(h, hipMalloc(&d_D.p, D.size()));
+    HIPCHK(h, dev_malloc(&d_D.p, D.size()));
     HIPCHK(h, hipMemcpyAsync(d_D.p, D.data(), D.size(), hipMemcpyHostToDevice, st));
     ConvParams p{};
     p.N = N; p.H = H; p.W = W; p.Hp = Hp; p.Wp = Wp; p.sHp = Hp; p.sWp = Wp;
@@ -1991,13 +2008,13 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
         if (!c5) {
             p.dst = (char*)d_D.p + (size_t)(Cin / 16) * blk; p.dst_img = dimg;       // the next growth slot of the same dense tensor
         } else {
-            HIPCHK(h, hipMalloc(&d_D2.p, D.size()));
+            HIPCHK(h, dev_malloc(&d_D2.p, D.size()));
             HIPCHK(h, hipMemsetAsync(d_D2.p, 0, D.size(), st));
             p.dst = (char*)d_D2.p; p.dst_img = dimg;
             std::vector<char> lo8((size_t)N * 2 * blk, 0), none;
             split64(a->lo, none, 0, &lo8, false);
-            HIPCHK(h, hipMalloc(&d_Tin.p, lo8.size()));
-            HIPCHK(h, hipMalloc(&d_Tout.p, lo8.size()));
+            HIPCHK(h, dev_malloc(&d_Tin.p, lo8.size()));
+            HIPCHK(h, dev_malloc(&d_Tout.p, lo8.size()));
             HIPCHK(h, hipMemcpyAsync(d_Tin.p, lo8.data(), lo8.size(), hipMemcpyHostToDevice, st));
             HIPCHK(h, hipMemsetAsync(d_Tout.p, 0, lo8.size(), st));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -2005,8 +2022,8 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
             if (rr) {
                 std::vector<char> shi((size_t)N * 4 * blk, 0), slo((size_t)N * 2 * blk, 0);
                 split64(a->skip, shi, 4 * blk, &slo, true);
-                HIPCHK(h, hipMalloc(&d_Sk.p, shi.size()));
-                HIPCHK(h, hipMalloc(&d_SkLo.p, slo.size()));
+                HIPCHK(h, dev_malloc(&d_Sk.p, shi.size()));
+                HIPCHK(h, dev_malloc(&d_SkLo.p, slo.size()));
                 HIPCHK(h, hipMemcpyAsync(d_Sk.p, shi.data(), shi.size(), hipMemcpyHostToDevice, st));
                 HIPCHK(h, hipMemcpyAsync(d_SkLo.p, slo.data(), slo.size(), hipMemcpyHostToDevice, st));
                 HIPCHK(h, hipStreamSynchronize(st));
@@ -2023,7 +2040,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
         if (!c5) {
             p.dst = (char*)d_D.p + (size_t)(Cin / 32) * blk; p.dst_img = dimg;
         } else {
-            HIPCHK(h, hipMalloc(&d_D2.p, D.size()));
+            HIPCHK(h, dev_malloc(&d_D2.p, D.size()));
             HIPCHK(h, hipMemsetAsync(d_D2.p, 0, D.size(), st));
             p.dst = (char*)d_D2.p; p.dst_img = dimg;
             std::vector<char> xin((size_t)N * 4 * blk, 0);      // the fp16 trunk = the first 64 of the Cin input channels
@@ -2033,8 +2050,8 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
                         for (int x = 0; x < W; ++x)
                             ((hf16*)(xin.data() + (size_t)n * 4 * blk + (size_t)(c >> 4) * blk + pix(y, x) * 32))[c & 15] =
                                 (hf16)a->x[(((size_t)n * Cin + c) * H + y) * W + x];
-            HIPCHK(h, hipMalloc(&d_Xin.p, xin.size()));
-            HIPCHK(h, hipMalloc(&d_Xout.p, xin.size()));
+            HIPCHK(h, dev_malloc(&d_Xin.p, xin.size()));
+            HIPCHK(h, dev_malloc(&d_Xout.p, xin.size()));
             HIPCHK(h, hipMemcpyAsync(d_Xin.p, xin.data(), xin.size(), hipMemcpyHostToDevice, st));
             HIPCHK(h, hipMemsetAsync(d_Xout.p, 0, xin.size(), st));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -2042,7 +2059,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
             if (rr) {
                 std::vector<char> shi((size_t)N * 4 * blk, 0);
                 split64(a->skip, shi, 4 * blk, nullptr, true);
-                HIPCHK(h, hipMalloc(&d_Sk.p, shi.size()));
+                HIPCHK(h, dev_malloc(&d_Sk.p, shi.size()));
                 HIPCHK(h, hipMemcpyAsync(d_Sk.p, shi.data(), shi.size(), hipMemcpyHostToDevice, st));
                 HIPCHK(h, hipStreamSynchronize(st));
                 p.xh_skip = (const char*)d_Sk.p;
@@ -2055,7 +2072,7 @@ int s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a) {
     // ---- read back and decode
     auto get = [&](const void* d, size_t bytes) -> int {
         tmp.resize(bytes);
-        HIPCHK(h, hipMemcpy(tmp.data(), d, bytes, hipMemcpyDeviceToHost));
+        HIPCHK(h, copy_blocking(h, tmp.data(), d, bytes, hipMemcpyDeviceToHost));
         return S2SR_OK;
     };
     int rc;
@@ -2117,12 +2134,12 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     unsigned long long* d_tr = nullptr;
     const bool wino = h->trunk_wino && h->trunk_w4 && cout == 32;
     const size_t wb = wino ? conv_wpack_bytes_wino(cin, cout) : conv_wpack_bytes(cin, cout), db = (size_t)N * 12 * blk;
-    HIPCHK(h, hipMalloc((void**)&D0, db));
-    HIPCHK(h, hipMalloc((void**)&D1, db));
-    HIPCHK(h, hipMalloc((void**)&T, (size_t)N * 4 * blk));
-    HIPCHK(h, hipMalloc((void**)&Rr, (size_t)N * 8 * blk));
-    HIPCHK(h, hipMalloc((void**)&d_w, wb));
-    HIPCHK(h, hipMalloc((void**)&d_b, 256));
+    HIPCHK(h, dev_malloc(&D0, db));
+    HIPCHK(h, dev_malloc(&D1, db));
+    HIPCHK(h, dev_malloc(&T, (size_t)N * 4 * blk));
+    HIPCHK(h, dev_malloc(&Rr, (size_t)N * 8 * blk));
+    HIPCHK(h, dev_malloc(&d_w, wb));
+    HIPCHK(h, dev_malloc(&d_b, 256));
     // pseudo-random fp16 bit patterns (finite, |v| < 2)
     std::vector<unsigned char> pat(db > wb ? db : wb);
     unsigned s = 12345u;
@@ -2156,7 +2173,7 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     HIPCHK(h, hipEventCreate(&e1));
     const bool timed_trace = trace && trace_wgs > 0 && getenv("S2SR_TRACE_TIMED");   // time the TRACE build (ablations)
     if (timed_trace) {
-        HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)256 * 24 * 8));
+        HIPCHK(h, dev_malloc(&d_tr, (size_t)256 * 24 * 8));
         p.trace = d_tr;
     }
     auto launch_one = [&](bool tr) -> hipError_t {
@@ -2178,17 +2195,17 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     *avg_us = ms * 1000.0f / iters;
     if (trace && trace_wgs > 0) {
         const int nwg = 256;
-        if (!d_tr) HIPCHK(h, hipMalloc((void**)&d_tr, (size_t)nwg * 24 * 8));
+        if (!d_tr) HIPCHK(h, dev_malloc(&d_tr, (size_t)nwg * 24 * 8));
         HIPCHK(h, hipMemset(d_tr, 0, (size_t)nwg * 24 * 8));
         p.trace = d_tr;
         HIPCHK(h, launch_one(true));
         HIPCHK(h, hipStreamSynchronize(st));
         const int nw = trace_wgs < nwg ? trace_wgs : nwg;
         HIPCHK(h, hipMemcpy(trace, d_tr, (size_t)nw * 24 * 8, hipMemcpyDeviceToHost));
-        hipFree(d_tr);
+        dev_free(d_tr);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(D0); hipFree(D1); hipFree(T); hipFree(Rr); hipFree(d_w); hipFree(d_b);
+    dev_free(D0); dev_free(D1); dev_free(T); dev_free(Rr); dev_free(d_w); dev_free(d_b);
     return S2SR_OK;
 }
 

@@ -97,8 +97,12 @@ hipError_t get_tables(PPTables** out) {
         PPTables* h = new PPTables();
         build_tables(*h);
         PPTables* d = nullptr;
-        e = hipMalloc((void**)&d, sizeof(PPTables));
-        if (e == hipSuccess) e = hipMemcpy(d, h, sizeof(PPTables), hipMemcpyHostToDevice);
+        e = dev_malloc(&d, sizeof(PPTables));
+        hipStream_t st = nullptr;                  // not the legacy stream: hipMemcpy fails (and breaks the capture) while any
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);   // other handle captures a graph
+        if (e == hipSuccess) e = hipMemcpyAsync(d, h, sizeof(PPTables), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (st) hipStreamDestroy(st);
         delete h;
         if (e != hipSuccess) return e;
         g_d_tables[dev] = d;

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/s2sr.h"
 
 // Kernel families and forms that the measurements buried (profiles/r0x_*) are compiled only with -DS2SR_EXPERIMENTAL=1
@@ -16,6 +18,27 @@
 #endif
 
 namespace s2sr {
+
+// ------------------------------------------------------------------------------------------
+// The device gate.  While a stream captures a hipGraph, the runtime refuses device-wide operations from EVERY thread of the
+// process (hipDeviceSynchronize, hipFree, legacy-stream hipMemcpy / hipMemset ...: "operation not permitted when stream is
+// capturing") and voids the capture with them.  Handles are independent objects used from different threads (the x4 and the
+// anime-6B engines under Starlette's pool, reference main.py:602,670-675), so one handle's workspace regrow met another's capture
+// (found by tools/soak_jobs.py, r04).  Rule of this library: no legacy-stream call anywhere (copy_blocking / fill_blocking in
+// engine.hip run on the handle's own stream), and every device-wide call goes through the wrappers below, which hold the same
+// process-wide mutex the capture section holds.  Captures are ~1 ms of host work and device-wide calls are rare (allocation,
+// regrow, teardown), so the gate costs nothing in steady state.
+// ------------------------------------------------------------------------------------------
+std::recursive_mutex& device_gate();
+struct DeviceGate {
+    std::lock_guard<std::recursive_mutex> lk;
+    DeviceGate() : lk(device_gate()) {}
+};
+static inline hipError_t dev_sync() { DeviceGate g; return hipDeviceSynchronize(); }
+template <class T> static inline hipError_t dev_malloc(T** p, size_t bytes) { DeviceGate g; return hipMalloc((void**)p, bytes); }
+static inline hipError_t dev_free(void* p) { DeviceGate g; return hipFree(p); }
+static inline hipError_t host_malloc(void** p, size_t bytes, unsigned flags) { DeviceGate g; return hipHostMalloc(p, bytes, flags); }
+static inline hipError_t host_free(void* p) { DeviceGate g; return hipHostFree(p); }
 
 // ------------------------------------------------------------------------------------------
 // Activation tensors in HBM: "blocked-16 with a physical zero halo".

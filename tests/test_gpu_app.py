@@ -7,6 +7,7 @@ import torch
 
 from oracle import postprocess_ref as pp
 from oracle import rrdbnet_ref as ref
+from s2sr import native
 from s2sr import rasterio_lite as rio
 from s2sr.weights import synthetic_state_dict
 
@@ -141,6 +142,48 @@ def test_concurrent_jobs_share_one_engine(monkeypatch, tmp_path):
     for tid in range(4):
         for i in range(len(imgs)):
             assert np.array_equal(results[tid][i], serial[i]), (tid, i)
+
+
+def test_two_engines_capture_and_regrow_on_two_threads():
+    """Two handles on two threads, as the x4 and the anime-6B engines are under Starlette's pool (main.py:602,670-675): while one
+    captures a hipGraph the other allocates and clears a bigger workspace, uploads stitch maps, loads weights.  None of that may
+    touch the legacy stream: the runtime refuses hipMemset / hipMemcpy while any stream of the process captures ("would make
+    the legacy stream depend on a capturing blocking stream") and voids the capture with it -- found by tools/soak_jobs.py."""
+    import threading
+    rng = np.random.default_rng(21)
+    shapes = [(40, 56), (64, 64), (33, 47), (90, 70), (128, 96), (50, 140), (160, 160), (200, 120)]
+    imgs = [rng.integers(0, 256, (*s, 3), dtype=np.uint8) for s in shapes]
+    sd = synthetic_state_dict(1, seed=4)
+    ref = native.Engine(num_block=1, precision=native.PREC_F16_HP)
+    ref.load_state_dict(sd)
+    serial = [ref.enhance_u8(im, tile=32, pad=4) for im in imgs]
+    ref.close()
+    errors, captures = [], [0, 0]
+    barrier = threading.Barrier(2)
+
+    def worker(tid):
+        try:
+            barrier.wait(10)
+            for rep in range(3):
+                e = native.Engine(num_block=1, precision=native.PREC_F16_HP)     # a fresh handle: every shape is a new capture
+                e.load_state_dict(sd)                                           # and most of them a bigger workspace
+                order = range(len(imgs)) if tid == 0 else reversed(range(len(imgs)))
+                for i in order:
+                    for again in range(2):                                      # graphs are captured at the second sighting
+                        if not np.array_equal(e.enhance_u8(imgs[i], tile=32, pad=4), serial[i]):
+                            errors.append((tid, rep, i, "pixels differ"))
+                captures[tid] += e.graph_stats()[0]
+                e.close()
+        except Exception as ex:                      # noqa: BLE001
+            errors.append((tid, repr(ex)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors[:4]
+    assert min(captures) > 0, captures
 
 
 def test_concurrent_postprocess_jobs_share_one_handle():

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Soak of the job layer on one GPU: worker threads run process_wow_sr jobs of changing sizes, models and options for a
+fixed time, as Starlette's pool does under load (reference main.py:247-368, 629-675).  Checks while it runs: every job's PNG is
+byte-identical to the first PNG produced for the same (input, options); device memory and host RSS settle after the first round of
+every shape.  Usage: tools/soak_jobs.py [seconds=120] [threads=4]"""
+import hashlib
+import os
+import sys
+import tempfile
+import threading
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+import numpy as np  # noqa: E402
+import psutil  # noqa: E402
+import torch  # noqa: E402
+
+from s2sr import rasterio_lite as rio  # noqa: E402
+from s2sr.weights import synthetic_state_dict  # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+tmp = Path(tempfile.mkdtemp())
+os.environ["S2SR_MODEL_DIR"] = str(tmp / "models")
+(tmp / "models").mkdir()
+for name, nb in (("realesrgan_x4", 23), ("realesrgan_anime", 6)):
+    sd = {k: torch.from_numpy(v) for k, v in synthetic_state_dict(nb, seed=nb).items()}
+    torch.save({"params_ema": sd}, tmp / "models" / f"{name}.pth")
+
+georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                     rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+rng = np.random.default_rng(0)
+inputs = []
+for i, (h, w) in enumerate([(256, 256), (300, 421), (512, 512), (97, 640), (700, 530), (64, 64)]):
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([110 + 70 * np.sin(xx / 23.0 + c) * np.cos(yy / 17.0) + rng.integers(-12, 13, (h, w)) for c in range(3)], -1)
+    p = tmp / f"in{i}.tif"
+    rio.write_geotiff_rgb(p, np.clip(rgb, 0, 255).astype(np.uint8), georef)
+    inputs.append(p)
+
+from app.wow_sr import process_wow_sr  # noqa: E402
+
+cases = [(p, ec, m) for p in inputs for ec in (True, False) for m in ("realesrgan_x4", "realesrgan_anime")]
+first, lock, counts, errors = {}, threading.Lock(), [0] * nthreads, []
+stop_at = time.time() + seconds
+
+
+def worker(t):
+    r = np.random.default_rng(100 + t)
+    k = 0
+    while time.time() < stop_at and not errors:
+        ci = int(r.integers(len(cases)))
+        p, ec, m = cases[ci]
+        out = tmp / f"out_{t}_{k % 4}"
+        try:
+            res = process_wow_sr(p, out, enhance_crops=ec, model=m)
+            d = hashlib.sha256(Path(res["outputs"]["sr_png"]).read_bytes()).hexdigest()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {t} case {ci}: {type(e).__name__}: {e}")
+            return
+        with lock:
+            if first.setdefault(ci, d) != d:
+                errors.append(f"thread {t} case {ci}: PNG differs from the first result of this case")
+        counts[t] += 1
+        k += 1
+
+
+def state():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2**20, psutil.Process().memory_info().rss / 2**20
+
+
+import contextlib  # noqa: E402
+import io  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):        # the reference's progress prints
+    for c in cases:                                    # one round of every case: engines, graphs, pools
+        first[cases.index(c)] = hashlib.sha256(Path(process_wow_sr(c[0], tmp / "warm", enhance_crops=c[1], model=c[2])["outputs"]["sr_png"]).read_bytes()).hexdigest()
+    f0, r0 = state()
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    t0 = time.time()
+    for t in ts:
+        t.start()
+    marks = []
+    while any(t.is_alive() for t in ts):
+        time.sleep(min(20.0, max(0.5, stop_at - time.time())))
+        marks.append((time.time() - t0, sum(counts), *state()))
+        print(f"  {marks[-1][0]:6.0f} s  {marks[-1][1]:5d} jobs  free device {marks[-1][2]:8.0f} MiB  host RSS {marks[-1][3]:7.0f} MiB", file=sys.stderr)
+    for t in ts:
+        t.join()
+f1, r1 = state()
+print(f"{sum(counts)} jobs over {len(cases)} cases in {time.time() - t0:.0f} s on {nthreads} threads ({counts}); errors: {errors or 'none'}")
+print(f"free device memory {f0:.0f} -> {f1:.0f} MiB; host RSS {r0:.0f} -> {r1:.0f} MiB")
+half = [m for m in marks if m[0] > marks[-1][0] / 2]
+print(f"second half of the run: free device {min(m[2] for m in half):.0f}..{max(m[2] for m in half):.0f} MiB, RSS {min(m[3] for m in half):.0f}..{max(m[3] for m in half):.0f} MiB")
+sys.exit(1 if errors else 0)
