@@ -1081,3 +1081,43 @@ def test_config3_full_size_batch64_postprocess():
     perm = np.random.default_rng(3).permutation(B)
     srp, outp = run(tiles[perm])
     assert np.array_equal(srp, sr[perm]) and np.array_equal(outp, out[perm])
+
+
+def test_shared_card_falls_back_to_smaller_groups_and_fails_loudly_when_nothing_fits():
+    """A card shared with other processes may not have the 12 GB a group of 16 tiles wants: the engine halves the group until the
+    workspace fits (same bytes for any group size), and when even one image does not fit the call fails with the sizes in the
+    message and the handle stays usable."""
+    rng = np.random.default_rng(31)
+    tiles = rng.integers(0, 256, size=(16, 256, 256, 3), dtype=np.uint8)
+    sd = synthetic_state_dict(1, seed=0)
+    want = engine(1, precision=native.PREC_F16_HP).forward_batch_u8(tiles)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def fill(leave_bytes):
+        blocks = []
+        while True:
+            free = torch.cuda.mem_get_info()[0]
+            n = min(free - leave_bytes, 32 << 30)
+            if n < (64 << 20):
+                return blocks
+            blocks.append(torch.empty(n, dtype=torch.uint8, device="cuda"))
+
+    e = native.Engine(num_block=1, precision=native.PREC_F16_HP)
+    e.load_state_dict(sd)
+    held = fill(5 << 30)                       # 5 GB left: groups of 16 and 8 do not fit, 4 does
+    try:
+        got = e.forward_batch_u8(tiles)
+        assert np.array_equal(got, want)
+        assert e.debug_config()["ws_allocs"] == 1
+        e.close()
+        e = native.Engine(num_block=1, precision=native.PREC_F16_HP)
+        e.load_state_dict(sd)
+        held += fill(300 << 20)                # 0.3 GB left: not even one image
+        with pytest.raises(native.S2srError, match="workspace of"):
+            e.forward_batch_u8(tiles)
+    finally:
+        del held
+        torch.cuda.empty_cache()
+    assert np.array_equal(e.forward_batch_u8(tiles), want)       # the same handle, once there is room again
+    e.close()
