@@ -129,11 +129,14 @@ def _adler32_combine(a1: int, a2: int, len2: int) -> int:
     return (s2 << 16) | s1
 
 
-def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None, strategy: Optional[int] = None) -> bytes:
-    """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> PNG bytes.  The SR outputs are tens of megapixels and PNG
-    deflate is what a job spends most of its time in, so the image is cut into bands that are filtered
-    (Sub) and deflated on a thread pool (zlib releases the GIL), each band ending on a sync flush so
-    that the pieces concatenate into one valid zlib stream (the pigz construction).
+def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None,
+                      strategy: Optional[int] = None) -> list:
+    """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> the PNG file as a list of byte strings to be written in order.  The SR outputs are
+    tens of megapixels and PNG deflate is what a job spends most of its time in, so the image is cut into bands that are filtered
+    (Sub) and deflated on a thread pool (zlib releases the GIL), each band ending on a sync flush so that the pieces concatenate
+    into one valid zlib stream (the pigz construction).  Every band is its own IDAT chunk (libpng writes many IDAT chunks too):
+    the chunk CRC is computed in the band's thread and nothing walks or copies the 30-MB stream afterwards (r04: one IDAT cost a
+    serial crc32 plus three copies of the stream, a quarter of the writer's time).
     Encoder settings = what `cv2.imwrite(path, img)` uses when the reference calls it without parameters (wow_sr.py:156,163;
     OpenCV 4.x grfmt_png.cpp: filter Sub, Z_BEST_SPEED, strategy Z_RLE): level 1 + Z_RLE, the fast end of deflate (r03 used
     level 3 with the default strategy: 118 ms of a 279 ms job for a 4096x4096 image).  Any setting decodes to the same pixels."""
@@ -148,6 +151,7 @@ def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: O
         raise ValueError(f"expected HxWx3 or HxWx4 uint8, got {img.shape} {img.dtype}")
     rows = img.reshape(h, w * c)
     bands = [(y, min(h, y + band_rows)) for y in range(0, h, band_rows)]
+    idat_crc0 = zlib.crc32(b"IDAT")
 
     def work(i):
         y0, y1 = bands[i]
@@ -155,11 +159,12 @@ def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: O
         raw = np.empty((y1 - y0, w * c + 1), np.uint8)
         raw[:, 0] = 1                                              # filter type Sub
         raw[:, 1:c + 1] = blk[:, :c]
-        raw[:, c + 1:] = blk[:, c:] - blk[:, :-c]
-        data = raw.tobytes()
+        np.subtract(blk[:, c:], blk[:, :-c], out=raw[:, c + 1:])
         co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_RLE if strategy is None else strategy)
-        out = co.compress(data) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
-        return out, zlib.adler32(data), len(data)
+        last = i == len(bands) - 1
+        out = (b"\x78\x5e" if i == 0 else b"") + co.compress(raw) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+        # the last band's chunk still lacks the stream's adler32: its CRC is finished by the caller
+        return out, zlib.adler32(raw), raw.size, (None if last else zlib.crc32(out, idat_crc0))
 
     n = workers or min(16, os.cpu_count() or 4)
     if len(bands) > 1 and n > 1:
@@ -168,21 +173,33 @@ def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: O
     else:
         parts = [work(i) for i in range(len(bands))]
     adler = 1
-    for _, a, ln in parts:
+    for _, a, ln, _ in parts:
         adler = _adler32_combine(adler, a, ln)
-    idat = b"\x78\x5e" + b"".join(p for p, _, _ in parts) + struct.pack(">I", adler)
 
     def chunk(kind: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
-    # IDAT payloads are capped at 2^31-1 bytes: split (a 16k x 16k RGB image stays far below)
-    idats = b"".join(chunk(b"IDAT", idat[i:i + (1 << 30)]) for i in range(0, len(idat), 1 << 30))
-    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)) +
-            idats + chunk(b"IEND", b""))
+    pieces = [b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))]
+    for i, (out, _, _, crc) in enumerate(parts):
+        tail = b""
+        if crc is None:
+            tail = struct.pack(">I", adler)
+            crc = zlib.crc32(tail, zlib.crc32(out, idat_crc0))
+        if len(out) + len(tail) >= (1 << 31):
+            raise ValueError("a band deflates to more than an IDAT chunk holds; lower band_rows")
+        pieces += [struct.pack(">I", len(out) + len(tail)) + b"IDAT", out, tail + struct.pack(">I", crc & 0xFFFFFFFF)]
+    pieces.append(chunk(b"IEND", b""))
+    return pieces
+
+
+def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None, strategy: Optional[int] = None) -> bytes:
+    """The pieces of `encode_png_pieces` as one byte string (for callers that want the file in memory)."""
+    return b"".join(encode_png_pieces(img, level, band_rows, workers, strategy))
 
 
 def write_png(path: Path, rgb: np.ndarray) -> None:
-    Path(path).write_bytes(encode_png(rgb))
+    with open(path, "wb") as f:
+        f.writelines(encode_png_pieces(rgb))
 
 
 def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoRef") -> None:
