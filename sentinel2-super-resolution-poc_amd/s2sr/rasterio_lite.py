@@ -166,9 +166,11 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
         # the last band's chunk still lacks the stream's adler32: its CRC is finished by the caller
         return out, zlib.adler32(raw), raw.size, (None if last else zlib.crc32(out, idat_crc0))
 
-    n = workers or min(16, os.cpu_count() or 4)
-    if len(bands) > 1 and n > 1:
-        with ThreadPoolExecutor(max_workers=n) as pool:
+    if len(bands) > 1 and workers is None:
+        from . import hostpool
+        parts = list(hostpool.pool().map(work, range(len(bands))))
+    elif len(bands) > 1 and workers > 1:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
             parts = list(pool.map(work, range(len(bands))))
     else:
         parts = [work(i) for i in range(len(bands))]
@@ -237,8 +239,8 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
     if c != 3:
         raise ValueError(f"expected HxWx3, got {rgb.shape}")
     strips = [(y, min(h, y + rows_per_strip)) for y in range(0, h, rows_per_strip)]
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
-        enc = list(pool.map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips))
+    from . import hostpool
+    enc = list(hostpool.pool().map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips))
     offs, pos = [], 8
     for e in enc:
         offs.append(pos)

@@ -199,11 +199,9 @@ def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
             out[y0:y0 + h, x0:x0 + w, :] = a[:h, :w, :]
 
     nchunks = nx * ny * planes
-    if comp != 1 and nchunks > 4 and H * W * spp * dt.itemsize > (1 << 22):
-        import os
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
-            list(pool.map(chunk, range(nchunks)))
+    if comp != 1 and nchunks >= 4 and H * W * spp * dt.itemsize >= (1 << 20):
+        from . import hostpool
+        list(hostpool.pool().map(chunk, range(nchunks)))
     else:
         for k in range(nchunks):
             chunk(k)
