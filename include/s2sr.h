@@ -33,6 +33,7 @@ extern "C" {
 #define S2SR_E_BADBLOB    -4   /* weight blob size does not match the configured net */
 #define S2SR_E_NODEVICE   -5   /* no gfx950 device visible: there is NO CPU fallback */
 #define S2SR_E_CAPACITY   -6   /* caller buffer too small */
+#define S2SR_E_IO         -7   /* a file could not be written (errno holds the reason) */
 
 /* arithmetic of the conv stack */
 #define S2SR_PREC_F16  0   /* fp16 operands, fp32 accumulate on MFMA; fp32 residual trunk  */
@@ -198,7 +199,9 @@ int  s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B,
  * base: tile pixel = rounded mean of the source pixels with alpha > 0 in columns col_lo..col_hi and
  *   rows row_lo..row_hi (tables of nx*256 and ny*256 entries, lo > hi = empty).
  * overview: parent pixel = rounded mean of the valid pixels of its 2x2 group in the child array;
- *   (ox, oy) = child-array tile coordinates of the first parent tile's north-west child (may be -1). */
+ *   (ox, oy) = child-array tile coordinates of the first parent tile's north-west child (may be -1).
+ *   child == NULL: the children are the level the previous base / overview call on this handle produced, taken from the
+ *   device copy (cnx, cny must match it; any other call on the handle in between invalidates the copy -> S2SR_E_INVALID). */
 int  s2sr_warp_bilinear_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, const float* grid, int32_t gh, int32_t gw,
                            int32_t step, int32_t OH, int32_t OW, uint8_t* out_rgba);
 int  s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W, const int32_t* col_lo, const int32_t* col_hi,
@@ -224,6 +227,27 @@ int  s2sr_graph_stats(s2sr_handle* h, int64_t* captures, int64_t* replays);
 int  s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
 /* the encoder for one strip (writes compress="lzw" GeoTIFFs, wow_sr.py:138-151); cap >= n*3/2 + 16 is always enough */
 int  s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+
+/* host-only PNG encoder for what the path writes (the reference calls cv2.imwrite(path, img) bare, server/app/wow_sr.py:156,163,
+ * and hands the tile pyramid to gdal2tiles, server/app/tiling.py:138-186): 8-bit RGB (channels 3) or RGBA (4), filter Sub on
+ * every row, deflate with distance-1 matches and dynamic Huffman blocks (cv2's Z_RLE / Z_BEST_SPEED settings, 3-4x zlib's speed).
+ * `px`: rows of `width * channels` bytes, `row_stride` bytes apart.  s2sr_png_bound() is always enough for `cap`. */
+size_t s2sr_png_bound(int32_t width, int32_t rows, int32_t channels);
+/* a complete PNG file (signature, IHDR, one IDAT, IEND) */
+int  s2sr_png_encode(const uint8_t* px, int32_t width, int32_t height, int32_t channels, size_t row_stride, uint8_t* out, size_t cap,
+                     size_t* out_n);
+/* one band of a big image as a complete IDAT chunk, so bands encode on parallel threads: `first` puts the zlib header in front,
+ * every band but the `last` ends on a sync flush (byte aligned), the last one on the final block.  The caller writes signature +
+ * IHDR, the bands' chunks in order, one more IDAT chunk holding the 4 bytes of the stream's Adler-32 (big endian; combine the
+ * per-band values `*adler` over `*raw_n` filtered bytes with adler32_combine), and IEND. */
+int  s2sr_png_idat_band(const uint8_t* px, int32_t width, int32_t rows, int32_t channels, size_t row_stride, int32_t first, int32_t last,
+                        uint8_t* out, size_t cap, size_t* out_n, uint32_t* adler, size_t* raw_n);
+/* `count` square tiles of `size` x `size` pixels, `tile_stride` bytes apart, each written to paths[t] as a PNG file (missing
+ * parent directories are created; paths[t] == NULL skips the tile).  skip_transparent: an RGBA tile whose alpha is 0 everywhere is
+ * not written (gdal2tiles writes no file for tiles outside the raster, reference server/app/tiling.py:138-186).  written[t]
+ * (optional) = 1 for the files written.  One call per tile row keeps the interpreter out of the 12.8k-tile loop of a pyramid. */
+int  s2sr_png_write_tiles(const uint8_t* tiles, int32_t count, int32_t size, int32_t channels, size_t tile_stride,
+                          const char* const* paths, int32_t skip_transparent, int32_t* written);
 
 /* test hook (host only, no GPU): the OCP e4m3fn encoder the weight packer uses for the fp8
  * correction stages -- round to nearest even, saturating at +-448, NaN -> 0x7f. */

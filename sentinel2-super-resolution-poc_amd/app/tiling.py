@@ -13,6 +13,7 @@ import json
 import logging
 import os
 import struct
+import threading
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
@@ -22,7 +23,7 @@ from typing import Optional
 import numpy as np
 from PIL import Image
 
-from s2sr import geo, native, tiles
+from s2sr import geo, hostpool, native, tiles
 from s2sr import rasterio_lite as rio
 from s2sr import tiff_lite
 
@@ -56,12 +57,15 @@ def _png_from_filtered(raw: np.ndarray, level: int, strategy: int) -> bytes:
 
 
 def encode_png_rgba(tile: np.ndarray, level: int = 1, strategy: int = zlib.Z_RLE) -> bytes:
-    """256x256x4 uint8 -> PNG bytes (8-bit RGBA, Sub filter on every row, one IDAT).  Plain zlib calls,
-    which release the GIL: tiles are encoded on a thread pool (gdal2tiles uses --processes 4 for this).  Level 1 + Z_RLE
-    (the fast end of deflate, what cv2.imwrite defaults to): r03's level 3 spent 2 s of a z10-18 pyramid in deflate."""
+    """256x256x4 uint8 -> PNG bytes (8-bit RGBA, Sub filter on every row, one IDAT).  The defaults (level 1 + Z_RLE, the fast
+    end of deflate, what cv2.imwrite uses) go through the native encoder (csrc/pngenc.hip, ~3x zlib on tile data, GIL released:
+    tiles are encoded on a thread pool; gdal2tiles uses --processes 4 for this); other settings through zlib."""
+    if level == 1 and strategy == zlib.Z_RLE:
+        return native.png_encode(tile)
     return _png_from_filtered(filter_sub_rgba(tile), level, strategy)
 
 _ENGINE: Optional[native.Engine] = None
+_PYRAMID_LOCK = threading.Lock()
 
 
 def _engine() -> native.Engine:
@@ -127,46 +131,58 @@ def reproject_to_web_mercator(input_path: Path, output_path: Path, resample_meth
     arr, _tags, place, crs = _read(input_path)
     rgb = rio._to_u8(arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
     plan = tiles.plan_warp(rgb.shape[1], rgb.shape[0], place, crs)
-    out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    with _PYRAMID_LOCK:          # the shared engine's scratch holds a pyramid chain's previous level (see _cut_pyramid)
+        out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
     output_path.parent.mkdir(parents=True, exist_ok=True)
     rio.write_geotiff_rgb(output_path, np.ascontiguousarray(out[..., :3]), _mercator_tags(plan.placement))
     logger.info("Reprojection complete: %s", output_path)
     return output_path
 
 
+LAST_STATS: dict = {}        # where the last process_raster_to_tiles / generate_xyz_tiles call spent its time (seconds; tools/bench_job.py)
+
+
 def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_zoom: int, max_zoom: int) -> None:
     """RGBA raster on the EPSG:3857 grid -> z/x/y.png files (deepest zoom from the raster, the others
     from their children); PNG encoding overlaps the next level's kernels on a thread pool."""
+    import time
     h, w = rgba.shape[:2]
     output_dir.mkdir(parents=True, exist_ok=True)
     eng = _engine()
     levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
 
     def write_tiles(args):
-        level_tiles, jj, ii, paths = args
-        for raw, path in zip(filter_sub_rgba(level_tiles[jj, ii]), paths):      # 8 tiles gathered and filtered per call
-            path.write_bytes(_png_from_filtered(raw, 1, zlib.Z_RLE))
+        # one task = up to 8 neighbouring tiles of one tile row, one native call: alpha check (tiles outside the raster are not
+        # written), filter + deflate, file write and mkdir-on-demand all run without the GIL.  (r04: the same steps from Python --
+        # alpha .any(), Path.write_bytes -- serialised 32 threads on the interpreter: 1.6 s for 12.8k tiles instead of 1.0)
+        level_tiles, zoom, j, i0, i1, tminx, yname = args
+        native.png_write_tiles(level_tiles[j, i0:i1], [f"{output_dir}/{zoom}/{tminx + i}/{yname}" for i in range(i0, i1)])
 
     prev, prev_lv = None, None
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+    t_dev = t_plan = 0.0
+    # the levels of one pyramid chain through the engine's device copy of the previous level: one pyramid at a time on the shared
+    # engine (the encoders of a finished chain keep running while the next job's chain starts)
+    with ThreadPoolExecutor(max_workers=hostpool.workers()) as pool:      # its own pool: tasks queue up level after level
         pending = []
-        for lv in levels:
-            if prev is None:
-                cur = eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h))
-            else:
-                ox, oy = tiles.overview_offsets(lv, prev_lv)
-                cur = eng.tiles_overview_u8(prev, ox, oy, lv.nx, lv.ny)
-            has_data = cur[..., 3].reshape(lv.ny, lv.nx, -1).any(-1)
-            for i in range(lv.nx):
-                if has_data[:, i].any():
-                    (output_dir / str(lv.zoom) / str(lv.tminx + i)).mkdir(parents=True, exist_ok=True)
-            jj, ii = np.nonzero(has_data)
-            paths = [output_dir / str(lv.zoom) / str(lv.tminx + i) / f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png" for j, i in zip(jj, ii)]
-            jobs = [(cur, jj[k:k + 8], ii[k:k + 8], paths[k:k + 8]) for k in range(0, len(paths), 8)]
-            pending.append(pool.map(write_tiles, jobs))                 # encoded while the next level is computed
-            prev, prev_lv = cur, lv
+        with _PYRAMID_LOCK:
+            for lv in levels:
+                t0 = time.perf_counter()
+                if prev is None:
+                    cur = eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h))
+                else:
+                    ox, oy = tiles.overview_offsets(lv, prev_lv)
+                    cur = eng.tiles_overview_u8(prev, ox, oy, lv.nx, lv.ny, on_device=True)    # children still on the device
+                t1 = time.perf_counter()
+                jobs = [(cur, lv.zoom, j, i0, min(lv.nx, i0 + 8), lv.tminx, f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png")
+                        for j in range(lv.ny) for i0 in range(0, lv.nx, 8)]
+                pending.append(pool.map(write_tiles, jobs))                 # encoded while the next level is computed
+                prev, prev_lv = cur, lv
+                t_dev += t1 - t0
+                t_plan += time.perf_counter() - t1
+        t0 = time.perf_counter()
         for p in pending:
             list(p)                                                     # surface any exception
+        LAST_STATS.update(pyramid_device_calls=t_dev, pyramid_listing=t_plan, pyramid_wait_for_encoders=time.perf_counter() - t0)
 
 
 def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, max_zoom: int = 16, tile_size: int = 256,
@@ -199,7 +215,10 @@ def create_tileset_metadata(tiles_dir: Path, bounds_4326: list, min_zoom: int, m
 
 def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 10, max_zoom: int = 16) -> dict:
     """Check the CRS, reproject if needed, cut the pyramid, write tileset.json."""
+    import time
     input_path, tiles_dir = Path(input_path), Path(tiles_dir)
+    LAST_STATS.clear()
+    t0 = time.perf_counter()
     arr, _tags, place, crs = _read(input_path)
     h, w, b = arr.shape
     west, south, east, north = place.bounds(w, h)
@@ -209,15 +228,38 @@ def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 1
     lon, lat = crs.to_lonlat(ex, ey)
     bounds_4326 = [float(lon.min()), float(lat.min()), float(lon.max()), float(lat.max())]
     rgb = rio._to_u8(arr[..., :3] if b >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
+    t1 = time.perf_counter()
+    LAST_STATS["read"] = t1 - t0
+    side = None
     if crs.epsg != 3857:
         # the warped raster is written next to the input like the reference does (<stem>_3857.tif, :251-252),
         # but the pyramid is cut from the array in hand, with the coverage mask of the warp as alpha
         plan = tiles.plan_warp(w, h, place, crs)
-        rgba = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
-        rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
-                              _mercator_tags(plan.placement))
+        t2 = time.perf_counter()
+        with _PYRAMID_LOCK:
+            rgba = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+        t3 = time.perf_counter()
         place = plan.placement
+        LAST_STATS.update(warp_plan=t2 - t1, warp_call=t3 - t2)
+        err = []
+
+        def write_3857():            # next to the pyramid, not in front of it: its strips fill the CPUs the device calls leave idle
+            try:
+                rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
+                                      _mercator_tags(plan.placement))
+            except BaseException as e:      # noqa: BLE001 -- surfaced below: a failed writer fails the call
+                err.append(e)
+        side = threading.Thread(target=write_3857)
+        side.start()
     else:
         rgba = np.dstack([rgb, np.full((h, w), 255, np.uint8)])
-    _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom)
+    t4 = time.perf_counter()
+    try:
+        _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom)
+    finally:
+        if side is not None:
+            side.join()
+    if side is not None and err:
+        raise err[0]
+    LAST_STATS["pyramid"] = time.perf_counter() - t4
     return create_tileset_metadata(tiles_dir, bounds_4326, min_zoom, max_zoom)

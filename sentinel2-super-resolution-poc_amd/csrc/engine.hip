@@ -122,6 +122,8 @@ struct s2sr_handle {
     // scratch device buffers (grown on demand)
     void* d_scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    int tiles_slot = -1;                 // scratch slot that still holds the tile level the last pyramid call produced (-1: none)
+    int tiles_nx = 0, tiles_ny = 0;
     // profiling
     int prof = 0;                 // 0 off, N>=1: bracket every N-th launch of each family with events
     bool span_on = false;         // a sampled span of consecutive launches of ONE family is open (span_begin / span_end): its launches
@@ -227,6 +229,7 @@ void drop_graphs(s2sr_handle* h) {   // buffers or weights moved: every captured
 }
 
 int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
+    h->tiles_slot = -1;                  // whoever asks for scratch is about to overwrite it; the pyramid calls set it again
     if (h->scratch_bytes[slot] >= bytes) return S2SR_OK;
     if (h->d_scratch[slot]) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1719,26 +1722,37 @@ int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W
     }
     HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    h->tiles_slot = 1; h->tiles_nx = nx; h->tiles_ny = ny;
     return S2SR_OK;
 }
 
 int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, int32_t cny, int32_t ox, int32_t oy, int32_t pnx,
                            int32_t pny, uint8_t* out) {
-    if (!h || !child || !out || cnx <= 0 || cny <= 0 || pnx <= 0 || pny <= 0) return S2SR_E_INVALID;
+    if (!h || !out || cnx <= 0 || cny <= 0 || pnx <= 0 || pny <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
     const size_t ib = (size_t)cnx * cny * 65536 * 4, ob = (size_t)pnx * pny * 65536 * 4;
+    // child == NULL: the children are the level the previous pyramid call on this handle produced, still on the device (a
+    // z18 level is 2.9 GB: sending it back costs as much as fetching it did)
+    int in_slot = 0;
+    if (!child) {
+        if (h->tiles_slot < 0 || h->tiles_nx != cnx || h->tiles_ny != cny)
+            return fail(h, S2SR_E_INVALID, "child == NULL, but the previous call on this handle did not leave a tile level of this size on the device");
+        in_slot = h->tiles_slot;
+    }
+    const int out_slot = in_slot == 1 ? 0 : 1;
     int rc;
-    if ((rc = ensure_scratch(h, 0, ib))) return rc;
-    if ((rc = ensure_scratch(h, 1, ob))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], child, ib, hipMemcpyHostToDevice, st));
+    if (child && (rc = ensure_scratch(h, in_slot, ib))) return rc;
+    if ((rc = ensure_scratch(h, out_slot, ob))) return rc;
+    if (child) HIPCHK(h, hipMemcpyAsync(h->d_scratch[in_slot], child, ib, hipMemcpyHostToDevice, st));
     {
         Scope sc(h, st, F_MISC, 0.0, (double)ib + (double)ob);
-        HIPCHK(h, launch_tiles_overview((const uint8_t*)h->d_scratch[0], cnx, cny, ox, oy, pnx, pny, (uint8_t*)h->d_scratch[1], st));
+        HIPCHK(h, launch_tiles_overview((const uint8_t*)h->d_scratch[in_slot], cnx, cny, ox, oy, pnx, pny, (uint8_t*)h->d_scratch[out_slot], st));
     }
-    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[out_slot], ob, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    h->tiles_slot = out_slot; h->tiles_nx = pnx; h->tiles_ny = pny;
     return S2SR_OK;
 }
 

@@ -78,10 +78,12 @@ extern "C" int s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, 
 // sizes dst as n*3/2 + 16.
 extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
     if ((!src && n) || !dst || !out_n) return S2SR_E_INVALID;
-    static const int HBITS = 14, HSIZE = 1 << HBITS;   // 4x the 4096 codes; entries carry a generation stamp
-    uint32_t hkey[HSIZE];                                // so a ClearCode does not cost a table wipe
-    uint16_t hval[HSIZE];
-    uint32_t gen = 1;
+    // dictionary: open addressing over 32768 slots of (prefix code 12 | byte 8 | code 12) bits.  What costs is the probe
+    // sequence of a MISS (on imagery most lookups miss: the string is new), so the table is kept nearly empty (load <= 0.12);
+    // measured on a 786-KB strip of SR output: 8192 slots 7.7 ms, 16384 5.4, 32768 5.0 (r03's separate key / value arrays with
+    // generation stamps, 16384 slots: 5.8).  A ClearCode wipes the table (128 KB per ~6.5 KB of incompressible input at worst).
+    static const int HBITS = 15, HSIZE = 1 << HBITS;
+    uint32_t tab[HSIZE];
     size_t pos = 0;
     uint64_t acc = 0;
     int nacc = 0;
@@ -95,10 +97,8 @@ extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, 
         }
         return true;
     };
-    memset(hkey, 0, sizeof hkey);
-    auto reset = [&]() {
-        if (++gen == (1u << 12)) { memset(hkey, 0, sizeof hkey); gen = 1; }
-    };
+    memset(tab, 0xFF, sizeof tab);                   // 0xFFFFFFFF: (prefix 4095, byte 255) -> code 4095 is never assigned
+    auto reset = [&]() { memset(tab, 0xFF, sizeof tab); };
     int next = 258, width = 9;
     if (!put(256, width)) return S2SR_E_CAPACITY;
     if (n == 0) {
@@ -107,16 +107,16 @@ extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, 
         int prefix = src[0];
         for (size_t i = 1; i < n; ++i) {
             const int k = src[i];
-            const uint32_t key = (gen << 20) | ((uint32_t)prefix << 8) | (uint32_t)k;   // 12 + 12 + 8 bits
-            uint32_t h = ((((uint32_t)prefix << 8) | (uint32_t)k) * 2654435761u) >> (32 - HBITS);
+            const uint32_t key = ((uint32_t)prefix << 8) | (uint32_t)k;                 // 12 + 8 bits
+            uint32_t h = (key * 2654435761u) >> (32 - HBITS);
             bool found = false;
-            while ((hkey[h] >> 20) == gen) {
-                if (hkey[h] == key) { found = true; break; }
+            while (tab[h] != 0xFFFFFFFFu) {
+                if ((tab[h] >> 12) == key) { found = true; break; }
                 h = (h + 1) & (HSIZE - 1);
             }
-            if (found) { prefix = hval[h]; continue; }
+            if (found) { prefix = (int)(tab[h] & 0xFFF); continue; }
             if (!put(prefix, width)) return S2SR_E_CAPACITY;
-            hkey[h] = key; hval[h] = (uint16_t)next++;
+            tab[h] = (key << 12) | (uint32_t)next++;
             if (next == 4094) {                       // table full: ClearCode at the current width, start over
                 if (!put(256, width)) return S2SR_E_CAPACITY;
                 reset();

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from pathlib import Path
 from typing import List, Optional
@@ -18,7 +19,7 @@ LIB_PATH = Path(os.environ.get("S2SR_LIB", _HERE.parent / "csrc" / "libs2sr.so")
 
 PREC_F16, PREC_F16_HP, PREC_FP8 = 0, 1, 2
 _ERR = {-1: "invalid argument", -2: "HIP error", -3: "weights not loaded", -4: "bad weight blob",
-        -5: "no gfx950 device (no CPU fallback exists)", -6: "buffer too small"}
+        -5: "no gfx950 device (no CPU fallback exists)", -6: "buffer too small", -7: "file could not be written"}
 
 
 class S2srError(RuntimeError):
@@ -110,6 +111,12 @@ _PROTOS = {
     "s2sr_tiles_overview_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
     "s2sr_tiff_lzw_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "s2sr_png_bound": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "s2sr_png_encode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "s2sr_png_idat_band": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]),
+    "s2sr_png_write_tiles": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_size_t, C.POINTER(C.c_char_p), C.c_int32,
+                                       C.POINTER(C.c_int32)]),
     "s2sr_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s2sr_debug_conv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p] +
                         [C.c_int32] * 3 + [C.c_void_p]),
@@ -185,6 +192,74 @@ def tiff_lzw_encode(data) -> bytes:
     if rc:
         raise S2srError(f"s2sr_tiff_lzw_encode: {_ERR.get(rc, rc)}")
     return out[:n.value].tobytes()
+
+
+def _png_rows(img: np.ndarray):
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4) or img.shape[0] < 1 or img.shape[1] < 1:
+        raise ValueError(f"expected HxWx3 or HxWx4 uint8, got {img.shape} {img.dtype}")
+    if img.strides[2] != 1 or img.strides[1] != img.shape[2] or img.strides[0] < img.shape[1] * img.shape[2]:
+        img = np.ascontiguousarray(img)
+    return img, img.shape[0], img.shape[1], img.shape[2], img.strides[0]
+
+
+_PNG_TLS = threading.local()
+
+
+def _png_out(cap: int) -> np.ndarray:
+    """Output staging of the calling thread (a fresh 300-KB array per tile is an mmap / munmap pair per call)."""
+    buf = getattr(_PNG_TLS, "buf", None)
+    if buf is None or buf.size < cap or buf.size > max(4 * cap, 1 << 22):
+        buf = _PNG_TLS.buf = np.empty(cap, np.uint8)
+    return buf
+
+
+def png_encode(img: np.ndarray) -> bytes:
+    """Host call (no GPU): HxWx3 / HxWx4 uint8 -> a complete PNG file (Sub filter, run-length deflate, dynamic Huffman).
+    ctypes drops the GIL: tiles encode in parallel on threads."""
+    lib = load_library()
+    img, h, w, c, stride = _png_rows(img)
+    cap = lib.s2sr_png_bound(w, h, c)
+    out = _png_out(cap)
+    n = C.c_size_t(0)
+    rc = lib.s2sr_png_encode(img.ctypes.data_as(C.c_void_p), w, h, c, stride, out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_png_encode: {_ERR.get(rc, rc)}")
+    return out[:n.value].tobytes()
+
+
+def png_idat_band(rows: np.ndarray, first: bool, last: bool):
+    """Host call (no GPU): a band of rows of a big image -> (one complete IDAT chunk, Adler-32 of the band's filtered bytes,
+    their count); see s2sr_png_idat_band in include/s2sr.h for how the bands make a file."""
+    lib = load_library()
+    rows, h, w, c, stride = _png_rows(rows)
+    cap = lib.s2sr_png_bound(w, h, c)
+    out = _png_out(cap)
+    n, adler, raw_n = C.c_size_t(0), C.c_uint32(0), C.c_size_t(0)
+    rc = lib.s2sr_png_idat_band(rows.ctypes.data_as(C.c_void_p), w, h, c, stride, int(first), int(last), out.ctypes.data_as(C.c_void_p),
+                                cap, C.byref(n), C.byref(adler), C.byref(raw_n))
+    if rc:
+        raise S2srError(f"s2sr_png_idat_band: {_ERR.get(rc, rc)}")
+    return out[:n.value].tobytes(), int(adler.value), int(raw_n.value)
+
+
+def png_write_tiles(tiles_arr: np.ndarray, paths, skip_transparent: bool = True) -> np.ndarray:
+    """Host call (no GPU): [n, S, S, 3|4] uint8 tiles -> PNG files at `paths` (str / Path, None = skip), parent directories made on
+    demand, fully transparent RGBA tiles skipped.  Returns the 0/1 array of files written.  The whole loop runs without the GIL."""
+    lib = load_library()
+    if tiles_arr.dtype != np.uint8 or tiles_arr.ndim != 4 or tiles_arr.shape[1] != tiles_arr.shape[2] or tiles_arr.shape[3] not in (3, 4):
+        raise ValueError(f"expected [n, S, S, 3|4] uint8, got {tiles_arr.shape} {tiles_arr.dtype}")
+    n, size, _, c = tiles_arr.shape
+    if len(paths) != n:
+        raise ValueError(f"{n} tiles, {len(paths)} paths")
+    if tiles_arr.strides[1:] != (size * c, c, 1) or tiles_arr.strides[0] < size * size * c:
+        tiles_arr = np.ascontiguousarray(tiles_arr)
+    cp = (C.c_char_p * n)(*[None if p is None else os.fsencode(p) for p in paths])
+    written = np.zeros(n, np.int32)
+    rc = lib.s2sr_png_write_tiles(tiles_arr.ctypes.data_as(C.c_void_p), n, size, c, tiles_arr.strides[0] if n else size * size * c, cp,
+                                  int(skip_transparent), written.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise S2srError(f"s2sr_png_write_tiles: {_ERR.get(rc, rc)}" + (f" ({os.strerror(C.get_errno())})" if rc == -7 and C.get_errno() else ""))
+    return written
 
 
 def tiff_lzw_decode(data: bytes, expected: int) -> bytes:
@@ -510,10 +585,16 @@ class Engine:
                                                  _ptr(t[3]), nx, ny, _ptr(out)), "s2sr_tiles_base_u8")
         return out
 
-    def tiles_overview_u8(self, child: np.ndarray, ox: int, oy: int, pnx: int, pny: int) -> np.ndarray:
-        child = np.ascontiguousarray(child, np.uint8)
+    def tiles_overview_u8(self, child: np.ndarray, ox: int, oy: int, pnx: int, pny: int, on_device: bool = False) -> np.ndarray:
+        """on_device: `child` is the array the previous tiles_base_u8 / tiles_overview_u8 call on this engine returned and nothing
+        else ran on the engine since: its device copy is used instead of uploading it again (only its shape is read)."""
         out = np.empty((pny, pnx, 256, 256, 4), np.uint8)
-        self._check(self._lib.s2sr_tiles_overview_u8(self._h, _ptr(child), child.shape[1], child.shape[0], ox, oy, pnx, pny, _ptr(out)),
+        if on_device:
+            src = None
+        else:
+            child = np.ascontiguousarray(child, np.uint8)
+            src = _ptr(child)
+        self._check(self._lib.s2sr_tiles_overview_u8(self._h, src, child.shape[1], child.shape[0], ox, oy, pnx, pny, _ptr(out)),
                     "s2sr_tiles_overview_u8")
         return out
 

@@ -132,18 +132,17 @@ def _adler32_combine(a1: int, a2: int, len2: int) -> int:
 def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None,
                       strategy: Optional[int] = None) -> list:
     """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> the PNG file as a list of byte strings to be written in order.  The SR outputs are
-    tens of megapixels and PNG deflate is what a job spends most of its time in, so the image is cut into bands that are filtered
-    (Sub) and deflated on a thread pool (zlib releases the GIL), each band ending on a sync flush so that the pieces concatenate
-    into one valid zlib stream (the pigz construction).  Every band is its own IDAT chunk (libpng writes many IDAT chunks too):
-    the chunk CRC is computed in the band's thread and nothing walks or copies the 30-MB stream afterwards (r04: one IDAT cost a
-    serial crc32 plus three copies of the stream, a quarter of the writer's time).
+    tens of megapixels and PNG deflate is what a job's writer spends its time in, so the image is cut into bands that are
+    filtered (Sub) and deflated in parallel, each band ending on a sync flush so that the pieces concatenate into one valid zlib
+    stream (the pigz construction).  Every band is its own IDAT chunk (libpng writes many IDAT chunks too): its CRC is computed
+    in the band's thread and nothing walks or copies the 30-MB stream afterwards.
     Encoder settings = what `cv2.imwrite(path, img)` uses when the reference calls it without parameters (wow_sr.py:156,163;
-    OpenCV 4.x grfmt_png.cpp: filter Sub, Z_BEST_SPEED, strategy Z_RLE): level 1 + Z_RLE, the fast end of deflate (r03 used
-    level 3 with the default strategy: 118 ms of a 279 ms job for a 4096x4096 image).  Any setting decodes to the same pixels."""
+    OpenCV 4.x grfmt_png.cpp: filter Sub, Z_BEST_SPEED, strategy Z_RLE).  With the defaults the bands go through the native
+    encoder (csrc/pngenc.hip: the same filter and run-length matching, 2-3x zlib's speed); `level` / `strategy` other than the
+    defaults select zlib.  Any setting decodes to the same pixels."""
     import struct
     import zlib
     from concurrent.futures import ThreadPoolExecutor
-    import os
 
     img = np.ascontiguousarray(img)
     h, w, c = img.shape
@@ -152,8 +151,14 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
     rows = img.reshape(h, w * c)
     bands = [(y, min(h, y + band_rows)) for y in range(0, h, band_rows)]
     idat_crc0 = zlib.crc32(b"IDAT")
+    use_native = level == 1 and strategy in (None, zlib.Z_RLE)
 
-    def work(i):
+    def work_native(i):                                            # -> (one complete IDAT chunk, adler, filtered bytes)
+        from . import native
+        y0, y1 = bands[i]
+        return native.png_idat_band(img[y0:y1], i == 0, i == len(bands) - 1)
+
+    def work_zlib(i):
         y0, y1 = bands[i]
         blk = rows[y0:y1]
         raw = np.empty((y1 - y0, w * c + 1), np.uint8)
@@ -161,11 +166,13 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
         raw[:, 1:c + 1] = blk[:, :c]
         np.subtract(blk[:, c:], blk[:, :-c], out=raw[:, c + 1:])
         co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_RLE if strategy is None else strategy)
-        last = i == len(bands) - 1
-        out = (b"\x78\x5e" if i == 0 else b"") + co.compress(raw) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
-        # the last band's chunk still lacks the stream's adler32: its CRC is finished by the caller
-        return out, zlib.adler32(raw), raw.size, (None if last else zlib.crc32(out, idat_crc0))
+        out = (b"\x78\x5e" if i == 0 else b"") + co.compress(raw) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        if len(out) >= (1 << 31):
+            raise ValueError("a band deflates to more than an IDAT chunk holds; lower band_rows")
+        piece = struct.pack(">I", len(out)) + b"IDAT" + out + struct.pack(">I", zlib.crc32(out, idat_crc0) & 0xFFFFFFFF)
+        return piece, zlib.adler32(raw), raw.size
 
+    work = work_native if use_native else work_zlib
     if len(bands) > 1 and workers is None:
         from . import hostpool
         parts = list(hostpool.pool().map(work, range(len(bands))))
@@ -175,23 +182,15 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
     else:
         parts = [work(i) for i in range(len(bands))]
     adler = 1
-    for _, a, ln, _ in parts:
+    for _, a, ln in parts:
         adler = _adler32_combine(adler, a, ln)
 
     def chunk(kind: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
-    pieces = [b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))]
-    for i, (out, _, _, crc) in enumerate(parts):
-        tail = b""
-        if crc is None:
-            tail = struct.pack(">I", adler)
-            crc = zlib.crc32(tail, zlib.crc32(out, idat_crc0))
-        if len(out) + len(tail) >= (1 << 31):
-            raise ValueError("a band deflates to more than an IDAT chunk holds; lower band_rows")
-        pieces += [struct.pack(">I", len(out) + len(tail)) + b"IDAT", out, tail + struct.pack(">I", crc & 0xFFFFFFFF)]
-    pieces.append(chunk(b"IEND", b""))
-    return pieces
+    # signature, IHDR, the bands' IDAT chunks, one small IDAT with the stream's Adler-32 (IDAT payloads concatenate), IEND
+    return ([b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))] +
+            [p for p, _, _ in parts] + [chunk(b"IDAT", struct.pack(">I", adler)) + chunk(b"IEND", b"")])
 
 
 def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None, strategy: Optional[int] = None) -> bytes:

@@ -60,10 +60,15 @@ def test_base_and_overview_bit_exact(eng):
     cur, cur_lv = base, lv
     for nxt in levels[1:]:
         ox, oy = tiles.overview_offsets(nxt, cur_lv)
-        got = eng.tiles_overview_u8(cur, ox, oy, nxt.nx, nxt.ny)
+        got = eng.tiles_overview_u8(cur, ox, oy, nxt.nx, nxt.ny, on_device=(nxt.zoom % 2 == 0))   # from the host copy / the device copy
         assert np.array_equal(got, ref.overview(cur, ox, oy, nxt.nx, nxt.ny)), nxt.zoom
         cur, cur_lv = got, nxt
     assert cur[..., 3].any()
+    with pytest.raises(native.S2srError, match="did not leave a tile level"):      # a level of another size is not "the previous level"
+        eng.tiles_overview_u8(np.zeros((cur.shape[0] + 1, cur.shape[1], 256, 256, 4), np.uint8), 0, 0, 1, 1, on_device=True)
+    eng.postprocess_u8(np.zeros((64, 64, 3), np.uint8), native.pp_wow())           # any other call takes the scratch
+    with pytest.raises(native.S2srError, match="did not leave a tile level"):
+        eng.tiles_overview_u8(cur, 0, 0, 1, 1, on_device=True)
     bad = tiles.plan_base(lv, place, 420, 300)
     bad[1][5] = 420                                             # a footprint that leaves the raster must be refused
     with pytest.raises(native.S2srError):

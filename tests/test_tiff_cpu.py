@@ -281,6 +281,85 @@ def test_malformed_tiffs_are_tiff_errors_and_stay_bounded(tmp_path, monkeypatch)
         tiff_lite.read_tiff(tmp_path / "big.tif")
 
 
+def test_native_png_encoder_decodes_to_the_input():
+    """csrc/pngenc.hip through the C ABI (s2sr_png_encode / s2sr_png_idat_band): PIL must read back the input pixels for noise
+    (stored blocks), constants (one run), upsampled and mixed content, strided views, and a Fibonacci histogram whose Huffman
+    tree is deeper than the 15 bits deflate allows (the length-limiting repair)."""
+    import io
+    import zlib
+    from s2sr import native
+    rng = np.random.default_rng(9)
+
+    def roundtrip(img, tag):
+        b = native.png_encode(img)
+        Image.open(io.BytesIO(b)).verify()                                  # chunk CRCs
+        got = np.asarray(Image.open(io.BytesIO(b)))
+        assert got.shape == img.shape and np.array_equal(got, img), tag
+        return b
+
+    for shape in ((1, 1, 3), (1, 1, 4), (2, 3, 3), (5, 7, 4), (256, 256, 4), (300, 257, 3), (257, 2, 3), (3, 5000, 4)):
+        roundtrip(rng.integers(0, 256, shape, dtype=np.uint8), ("noise", shape))
+        roundtrip(np.zeros(shape, np.uint8), ("zeros", shape))
+        up = np.repeat(np.repeat(rng.integers(0, 256, (shape[0] // 6 + 1, shape[1] // 6 + 1, shape[2]), dtype=np.uint8), 6, 0), 6, 1)
+        roundtrip(np.ascontiguousarray(up[:shape[0], :shape[1]]), ("upsampled", shape))
+        m = rng.integers(0, 256, shape, dtype=np.uint8)
+        m[rng.random(shape[:2]) < 0.7] = 7
+        roundtrip(m, ("mixed", shape))
+    f = [1, 1]
+    while len(f) < 24:
+        f.append(f[-1] + f[-2])
+    vals = np.concatenate([np.full(c, v * 7 % 256, np.uint8) for v, c in enumerate(f)])
+    rng.shuffle(vals)
+    roundtrip(vals[:vals.size // 12 * 12].reshape(-1, 4, 3), "fibonacci")
+    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    roundtrip(big[10:200, 20:300], "view")
+    # a compressible tile must actually compress, about as well as zlib with the same settings
+    yy, xx = np.mgrid[0:256, 0:256]
+    tile = np.empty((256, 256, 4), np.uint8)
+    tile[..., :3] = np.clip(110 + 70 * np.sin(xx / 140.0)[..., None] * np.cos(yy / 100.0)[..., None]
+                            + np.repeat(np.repeat(rng.integers(-12, 13, (43, 43, 3)), 6, 0), 6, 1)[:256, :256], 0, 255)
+    tile[..., 3] = 255
+    from app.tiling import _png_from_filtered, filter_sub_rgba
+    ref = _png_from_filtered(filter_sub_rgba(tile), 1, zlib.Z_RLE)
+    assert len(roundtrip(tile, "tile")) < 1.03 * len(ref)
+    # the banded writer on both routes (native: level 1 + Z_RLE; zlib: anything else)
+    a = rng.integers(0, 256, (300, 401, 3), dtype=np.uint8)
+    a[50:200] = 9
+    for kw in (dict(), dict(level=3), dict(strategy=zlib.Z_DEFAULT_STRATEGY)):
+        for workers in (None, 1, 4):
+            got = np.asarray(Image.open(io.BytesIO(rio.encode_png(a, band_rows=64, workers=workers, **kw))))
+            assert np.array_equal(got, a), (kw, workers)
+    with pytest.raises(ValueError):
+        native.png_encode(np.zeros((4, 4, 2), np.uint8))
+
+
+def test_native_tile_writer(tmp_path):
+    """s2sr_png_write_tiles: a row of RGBA tiles -> z/x/y.png files in one native call (directories on demand, fully transparent
+    tiles skipped, None paths skipped), and an unwritable path is an error, not a silent loss."""
+    from s2sr import native
+    rng = np.random.default_rng(4)
+    t = rng.integers(0, 256, (5, 64, 64, 4), dtype=np.uint8)
+    t[..., 3] = 255
+    t[1, ..., 3] = 0                                   # outside the raster
+    t[2, :, :32, 3] = 0                                # half covered: written
+    paths = [tmp_path / "18" / str(100 + i) / "7.png" for i in range(5)]
+    paths[3] = None
+    wrote = native.png_write_tiles(t, paths)
+    assert wrote.tolist() == [1, 0, 1, 0, 1]
+    assert not (tmp_path / "18" / "101").exists() and not (tmp_path / "18" / "103").exists()
+    for i in (0, 2, 4):
+        assert np.array_equal(np.asarray(Image.open(paths[i])), t[i])
+    assert native.png_write_tiles(t[1:2], [tmp_path / "x.png"], skip_transparent=False).tolist() == [1]
+    big = rng.integers(0, 256, (2, 3, 64, 64, 4), dtype=np.uint8)               # a slice of a level array: tiles one stride apart
+    native.png_write_tiles(big[1, 0:2], [tmp_path / "a.png", tmp_path / "b.png"], skip_transparent=False)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "b.png")), big[1, 1])
+    (tmp_path / "file").write_bytes(b"x")
+    with pytest.raises(native.S2srError, match="could not be written"):
+        native.png_write_tiles(t[:1], [tmp_path / "file" / "sub" / "1.png"])
+    with pytest.raises(ValueError):
+        native.png_write_tiles(t, paths[:2])
+
+
 def test_host_codec_under_address_and_ub_sanitizers(tmp_path):
     """csrc/hostcodec.hip holds no device code: built with g++ -fsanitize=address,undefined into tests/native/fuzz_hostcodec.cpp's
     harness (round trips at exact buffer sizes, short buffers, truncated / bit-flipped / random streams)."""
@@ -300,3 +379,14 @@ def test_host_codec_under_address_and_ub_sanitizers(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([str(exe), "1500"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok 1500 cases" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    # the PNG encoder: every file parsed, inflated with zlib and un-filtered back to the pixels; exact-size buffers
+    exe2 = tmp_path / "fuzz_pngenc"
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-x", "c++",
+                        str(root / "tests" / "native" / "fuzz_pngenc.cpp"),
+                        str(root / "sentinel2-super-resolution-poc_amd" / "csrc" / "pngenc.hip"), "-lz", "-o", str(exe2)],
+                       capture_output=True, text=True, timeout=300)
+    if b.returncode != 0 and ("zlib.h" in b.stderr or "-lz" in b.stderr):
+        pytest.skip("zlib development files not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([str(exe2), "400"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok 400 cases" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])

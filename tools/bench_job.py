@@ -66,3 +66,5 @@ meta = process_raster_to_tiles(sr_tif, tmp / "tiles", 10, 18)
 dt = time.perf_counter() - t0
 ntiles = sum(1 for _ in (tmp / "tiles").glob("*/*/*.png"))
 print(f"process_raster_to_tiles z10..18: {ntiles} tiles in {dt*1e3:.0f} ms")
+import app.tiling as tl  # noqa: E402
+print("  " + ", ".join(f"{k} {v*1e3:.0f} ms" for k, v in tl.LAST_STATS.items()))
