@@ -122,6 +122,7 @@ struct s2sr_handle {
     // scratch device buffers (grown on demand)
     void* d_scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    int capture_failures = 0;            // captures voided by a device-wide call of another runtime user; 3 -> graphs off
     int tiles_slot = -1;                 // scratch slot that still holds the tile level the last pyramid call produced (-1: none)
     int tiles_nx = 0, tiles_ny = 0;
     // profiling
@@ -227,6 +228,34 @@ void drop_graphs(s2sr_handle* h) {   // buffers or weights moved: every captured
         if (g.exec) hipGraphExecDestroy(g.exec);
     h->graphs.clear();
 }
+
+// A capture that another user of the runtime voided (their hipDeviceSynchronize / hipFree while this handle captured: the device
+// gate only covers this library) leaves the stream in the "invalidated" state for good -- hipStreamEndCapture reports the error
+// but every later operation on the stream still fails.  The host-facing calls that run on the handle's own stream check for that
+// after a failure, replace the stream and run again (inputs are untouched, outputs are rewritten); after three such captures
+// the handle stops capturing.  Callers that pass their own stream (the *_dev calls) get the error.
+bool recover_stream(s2sr_handle* h) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return false;
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    const hipError_t e = hipStreamIsCapturing(h->stream, &status);
+    (void)hipGetLastError();
+    if (e == hipSuccess && status == hipStreamCaptureStatusNone) return false;       // the failure was something else
+    hipStream_t fresh = nullptr;
+    if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) return false;
+    hipStreamDestroy(h->stream);
+    (void)hipGetLastError();
+    h->stream = fresh;
+    drop_graphs(h);
+    if (++h->capture_failures >= 3) h->graphs_on = false;
+    return true;
+}
+#define RUN_WITH_STREAM_RECOVERY(h, call)            \
+    do {                                             \
+        int rc_ = (call);                            \
+        if (rc_ != S2SR_OK && (h) && recover_stream(h)) rc_ = (call); \
+        return rc_;                                  \
+    } while (0)
 
 int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
     h->tiles_slot = -1;                  // whoever asks for scratch is about to overwrite it; the pyramid calls set it again
@@ -1207,7 +1236,7 @@ int s2sr_host_free(void* p) {
     return S2SR_OK;
 }
 
-int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, uint8_t* out) {
+static int forward_batch_u8_once(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, uint8_t* out) {
     if (!h || !tiles || !out) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1247,7 +1276,11 @@ int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32
     return S2SR_OK;
 }
 
-int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32_t W, float* y) {
+int s2sr_forward_batch_u8(s2sr_handle* h, const uint8_t* tiles, int32_t B, int32_t th, int32_t tw, uint8_t* out) {
+    RUN_WITH_STREAM_RECOVERY(h, forward_batch_u8_once(h, tiles, B, th, tw, out));
+}
+
+static int forward_f32_once(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32_t W, float* y) {
     if (!h || !x || !y) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1262,6 +1295,10 @@ int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32
     HIPCHK(h, hipMemcpyAsync(y, h->d_scratch[1], ob, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return S2SR_OK;
+}
+
+int s2sr_forward_f32(s2sr_handle* h, const float* x, int32_t N, int32_t H, int32_t W, float* y) {
+    RUN_WITH_STREAM_RECOVERY(h, forward_f32_once(h, x, N, H, W, y));
 }
 
 // host-side maps of the paste rule; shared by enhance and the multi-GPU stitch
@@ -1530,18 +1567,18 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
 }
 
 int s2sr_enhance_u8(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, uint8_t* out) {
-    return enhance_impl(h, img, H, W, tile, pad, out, nullptr);
+    RUN_WITH_STREAM_RECOVERY(h, enhance_impl(h, img, H, W, tile, pad, out, nullptr));
 }
 
 // A whole /api/wow job's device work in one call (apply_wow_sr, wow_sr.py:85-110): RGB image in, RGB2BGR, RealESRGAN.enhance,
 // BGR2RGB, _enhance_for_crops (prm != NULL), RGB image out -- one upload, one download, nothing in between on the host.
 int s2sr_enhance_job_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t W, int32_t tile, int32_t pad, const s2sr_pp_params* prm,
                         uint8_t* out_rgb) {
-    return enhance_impl(h, rgb, H, W, tile, pad, out_rgb, nullptr, false, true, prm);
+    RUN_WITH_STREAM_RECOVERY(h, enhance_impl(h, rgb, H, W, tile, pad, out_rgb, nullptr, false, true, prm));
 }
 
 int s2sr_enhance_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
-    return enhance_impl(h, img, H, W, tile, pad, nullptr, out);
+    RUN_WITH_STREAM_RECOVERY(h, enhance_impl(h, img, H, W, tile, pad, nullptr, out));
 }
 
 int s2sr_cut_windows_u8_dev(s2sr_handle* h, const void* d_img, int32_t H, int32_t W, int32_t tile, int32_t pad,
@@ -1627,7 +1664,7 @@ int s2sr_copy_to_host(s2sr_handle* h, void* dst, const void* d_src, size_t bytes
 }
 
 int s2sr_tile_process_f32(s2sr_handle* h, const uint8_t* img, int32_t H, int32_t W, int32_t tile, int32_t pad, float* out) {
-    return enhance_impl(h, img, H, W, tile, pad, nullptr, out, true);
+    RUN_WITH_STREAM_RECOVERY(h, enhance_impl(h, img, H, W, tile, pad, nullptr, out, true));
 }
 
 // post-process on device buffers; the caller holds h->mu

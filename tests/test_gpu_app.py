@@ -186,6 +186,45 @@ def test_two_engines_capture_and_regrow_on_two_threads():
     assert min(captures) > 0, captures
 
 
+def test_capture_voided_by_another_runtime_user_is_recovered():
+    """Another user of the HIP runtime in the process (here: a thread in torch.cuda.synchronize / allocator traffic) voids a graph
+    capture in progress -- the library's gate cannot see it -- and the runtime leaves the stream unusable.  The host-facing calls
+    replace the stream and run again: no error reaches the caller, the bytes are the serial ones, and after three voided
+    captures the handle stops capturing.  (The other thread's own call fails with hipErrorStreamCaptureUnsupported while a
+    capture is open: runtime behaviour, INTEGRATION.md "Threads".)"""
+    import threading
+    rng = np.random.default_rng(5)
+    sd = synthetic_state_dict(1, seed=4)
+    imgs = [rng.integers(0, 256, (40 + 8 * i, 56 + 4 * i, 3), dtype=np.uint8) for i in range(30)]
+    ref = native.Engine(num_block=1, precision=native.PREC_F16_HP)
+    ref.load_state_dict(sd)
+    serial = [ref.enhance_u8(im, tile=32, pad=4) for im in imgs]
+    ref.close()
+    stop = threading.Event()
+    refused = [0]
+
+    def pest():
+        while not stop.is_set():
+            try:
+                torch.cuda.synchronize()
+                torch.empty(1 << 20, device="cuda")
+            except Exception:                      # noqa: BLE001 -- the runtime refuses these while a capture is open
+                refused[0] += 1
+    t = threading.Thread(target=pest)
+    t.start()
+    try:
+        e = native.Engine(num_block=1, precision=native.PREC_F16_HP)
+        e.load_state_dict(sd)
+        for rep in range(3):
+            for i, im in enumerate(imgs):
+                assert np.array_equal(e.enhance_u8(im, tile=32, pad=4), serial[i]), (rep, i)
+    finally:
+        stop.set()
+        t.join()
+    assert np.array_equal(e.enhance_u8(imgs[0], tile=32, pad=4), serial[0])
+    e.close()
+
+
 def test_concurrent_postprocess_jobs_share_one_handle():
     """The app keeps ONE post-process handle per GPU (app.wow_sr._pp_engine) and the reference runs jobs
     from concurrent worker threads (main.py:247-368, 629-675): 4 threads x different images of different
