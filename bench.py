@@ -14,7 +14,7 @@ checkpoints offline), broadcast from rank 0 over RCCL.
 Behind the headline and OUTSIDE its timed region the same line carries:
   N > 1:  `aoi_strong_scaling` -- BASELINE configs[2]: one 4096x4096 AOI sharded over the N ranks (strong scaling), host image
           out on rank 0 (s2sr.dist.enhance_distributed);
-  N = 1:  `secondary` -- the fp8 trunk line (configs[4] arithmetic, outside the 1e-3 tolerance), the 4096x4096 and 1024x1024 AOIs
+  N = 1:  `secondary` -- the fp8 trunk line (configs[4] arithmetic, outside the 1e-3 tolerance), a whole /api/wow job (`job_1024`), the 4096x4096 and 1024x1024 AOIs
           through s2sr_enhance_u8, the 4096x4096 AOI through the multi-GPU orchestration with one rank over RCCL, configs[3]
           (64 tiles + the enhance_crops post-process), one tile's latency (256x256 and 64x64); and `cpu_baseline`.
 """
@@ -235,6 +235,56 @@ PROF_EVERY = 7               # coprime with the period of the conv5 / conv5-of-r
                              # marker packets between all kernels and inflates a 70 us kernel's time by ~13 % against rocprofv3's kernel
                              # duration (measured).  conv1-4 are sampled as SPANS: one event pair around the four conv1..4 launches of
                              # every 7th RDB (engine.hip span_begin / span_end), which spreads the pair's cost over four launches
+
+
+def job_leg(side: int = 1024) -> dict:
+    """A whole /api/wow job through the reference-shaped seam (app.wow_sr.process_wow_sr, reference server/app/main.py:290-368): a
+    side x side GeoTIFF on disk -> SR net + crop-visibility post-process (one native call) -> x4 GeoTIFF (LZW) + PNG on disk, then
+    the z10-18 XYZ tile pyramid of the result (app.tiling.process_raster_to_tiles).  Host codecs, file I/O and PCIe included:
+    wall-clock milliseconds, not a throughput; the first call of the process is reported apart."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from s2sr import rasterio_lite as rio
+    tmp = Path(tempfile.mkdtemp(prefix="s2sr_bench_job_"))
+    old_dir = os.environ.get("S2SR_MODEL_DIR")
+    try:
+        os.environ["S2SR_MODEL_DIR"] = str(tmp / "models")
+        (tmp / "models").mkdir()
+        torch.save({"params_ema": {k: torch.from_numpy(v) for k, v in synthetic_state_dict(NUM_BLOCK, seed=0).items()}},
+                   tmp / "models" / "realesrgan_x4.pth")
+        yy, xx = np.mgrid[0:side, 0:side]
+        rng = np.random.default_rng(0)
+        rgb = np.stack([110 + 70 * np.sin(xx / 23.0 + c) * np.cos(yy / 17.0) + rng.integers(-12, 13, (side, side)) for c in range(3)], -1)
+        georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                             rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+        rio.write_geotiff_rgb(tmp / "aoi.tif", np.clip(rgb, 0, 255).astype(np.uint8), georef)
+        import app.tiling as tiling
+        from app.wow_sr import process_wow_sr
+        times = []
+        with contextlib.redirect_stdout(io.StringIO()):          # the reference's progress prints
+            for i in range(5):
+                t0 = time.perf_counter()
+                res = process_wow_sr(tmp / "aoi.tif", tmp / f"run{i % 2}")
+                times.append((time.perf_counter() - t0) * 1e3)
+        sr_tif = Path(res["outputs"]["sr_tif"])
+        tiling.process_raster_to_tiles(sr_tif, tmp / "tiles_warm", 10, 12)
+        t0 = time.perf_counter()
+        tiling.process_raster_to_tiles(sr_tif, tmp / "tiles", 10, 18)
+        t_tiles = (time.perf_counter() - t0) * 1e3
+        ntiles = sum(1 for _ in (tmp / "tiles").glob("*/*/*.png"))
+        return {"ms": round(min(times[2:]), 1), "first_call_ms": round(times[0], 1), "second_call_ms": round(times[1], 1),
+                "tile_pyramid_ms": round(t_tiles, 1), "tiles": ntiles,
+                "tile_pyramid_stages_ms": {k: round(v * 1e3, 1) for k, v in tiling.LAST_STATS.items()},
+                "workload": f"process_wow_sr on a {side}x{side} UTM GeoTIFF (enhance_crops on, tile 256 / pad 10) -> {4 * side}x{4 * side} LZW GeoTIFF + PNG "
+                            "on disk; then process_raster_to_tiles z10..18 of the SR GeoTIFF (EPSG:3857 warp, RGBA PNG tiles); best of 3 warm runs"}
+    finally:
+        if old_dir is None:
+            os.environ.pop("S2SR_MODEL_DIR", None)
+        else:
+            os.environ["S2SR_MODEL_DIR"] = old_dir
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def roofline_block(stats: dict, precision: str, group: int, batch: int, dt_prof: float, steps: int, g0, g1) -> dict:
@@ -616,6 +666,10 @@ def main():
                 eng.forward_batch_u8_dev(x1.data_ptr(), 1, S, S, y1.data_ptr(), stream)
             torch.cuda.synchronize()
             sec[key] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+        try:
+            sec["job_1024"] = job_leg(1024)
+        except Exception as e:      # noqa: BLE001 -- a side leg must not cost the headline line
+            sec["job_1024"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line["secondary"] = sec
     if rank == 0:
