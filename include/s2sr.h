@@ -208,6 +208,14 @@ int  s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t 
                         const int32_t* row_lo, const int32_t* row_hi, int32_t nx, int32_t ny, uint8_t* out);
 int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, int32_t cny, int32_t ox, int32_t oy, int32_t pnx,
                             int32_t pny, uint8_t* out);
+/* base / overview with out == NULL: the level is computed and stays on the device (for s2sr_tiles_write_png and as the next
+ * overview's children).
+ * write_png: the PNG files (8-bit RGBA, what s2sr_png_encode writes up to the tokenisation: runs do not cross rows) of the level the
+ * previous base / overview call produced, encoded on the device: token statistics and bit emission are kernels, the Huffman codes
+ * come from the host between them, only compressed bytes cross PCIe.  paths: nx * ny entries, row-major like the tile array, NULL =
+ * skip; skip_transparent: no file for a tile whose alpha is 0 everywhere; written (optional): 1 per file written.  Missing parent
+ * directories are created. */
+int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t skip_transparent, int32_t* written);
 
 /* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;
  * on = N >= 1: every N-th launch of each family is bracketed by a hipEvent pair (N > 1 keeps

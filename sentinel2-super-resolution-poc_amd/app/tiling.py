@@ -11,11 +11,9 @@ from __future__ import annotations
 
 import json
 import logging
-import os
 import struct
 import threading
 import zlib
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional
@@ -23,7 +21,7 @@ from typing import Optional
 import numpy as np
 from PIL import Image
 
-from s2sr import geo, hostpool, native, tiles
+from s2sr import geo, native, tiles
 from s2sr import rasterio_lite as rio
 from s2sr import tiff_lite
 
@@ -143,46 +141,34 @@ LAST_STATS: dict = {}        # where the last process_raster_to_tiles / generate
 
 
 def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_zoom: int, max_zoom: int) -> None:
-    """RGBA raster on the EPSG:3857 grid -> z/x/y.png files (deepest zoom from the raster, the others
-    from their children); PNG encoding overlaps the next level's kernels on a thread pool."""
+    """RGBA raster on the EPSG:3857 grid -> z/x/y.png files (deepest zoom from the raster, the others from their children).
+    The levels never leave the device as pixels: each is computed from the previous one's device copy and its PNG files are encoded
+    there (s2sr_tiles_write_png: token statistics and bit emission are kernels, the Huffman codes come from the host in between;
+    chunk framing, CRC and the file writes run on native host threads).  r04, same 12.8k-tile pyramid: levels fetched and deflated
+    by zlib on a Python pool 1.9 s -> native host encoder, one call per 8 tiles 0.6 s -> encoded on the device (this)."""
     import time
     h, w = rgba.shape[:2]
     output_dir.mkdir(parents=True, exist_ok=True)
     eng = _engine()
     levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
-
-    def write_tiles(args):
-        # one task = up to 8 neighbouring tiles of one tile row, one native call: alpha check (tiles outside the raster are not
-        # written), filter + deflate, file write and mkdir-on-demand all run without the GIL.  (r04: the same steps from Python --
-        # alpha .any(), Path.write_bytes -- serialised 32 threads on the interpreter: 1.6 s for 12.8k tiles instead of 1.0)
-        level_tiles, zoom, j, i0, i1, tminx, yname = args
-        native.png_write_tiles(level_tiles[j, i0:i1], [f"{output_dir}/{zoom}/{tminx + i}/{yname}" for i in range(i0, i1)])
-
-    prev, prev_lv = None, None
-    t_dev = t_plan = 0.0
-    # the levels of one pyramid chain through the engine's device copy of the previous level: one pyramid at a time on the shared
-    # engine (the encoders of a finished chain keep running while the next job's chain starts)
-    with ThreadPoolExecutor(max_workers=hostpool.workers()) as pool:      # its own pool: tasks queue up level after level
-        pending = []
-        with _PYRAMID_LOCK:
-            for lv in levels:
-                t0 = time.perf_counter()
-                if prev is None:
-                    cur = eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h))
-                else:
-                    ox, oy = tiles.overview_offsets(lv, prev_lv)
-                    cur = eng.tiles_overview_u8(prev, ox, oy, lv.nx, lv.ny, on_device=True)    # children still on the device
-                t1 = time.perf_counter()
-                jobs = [(cur, lv.zoom, j, i0, min(lv.nx, i0 + 8), lv.tminx, f"{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png")
-                        for j in range(lv.ny) for i0 in range(0, lv.nx, 8)]
-                pending.append(pool.map(write_tiles, jobs))                 # encoded while the next level is computed
-                prev, prev_lv = cur, lv
-                t_dev += t1 - t0
-                t_plan += time.perf_counter() - t1
-        t0 = time.perf_counter()
-        for p in pending:
-            list(p)                                                     # surface any exception
-        LAST_STATS.update(pyramid_device_calls=t_dev, pyramid_listing=t_plan, pyramid_wait_for_encoders=time.perf_counter() - t0)
+    prev_lv = None
+    t_dev = t_png = 0.0
+    # the levels of one pyramid chain through the engine's device copy of the previous level: one pyramid at a time on the shared engine
+    with _PYRAMID_LOCK:
+        for lv in levels:
+            t0 = time.perf_counter()
+            if prev_lv is None:
+                eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h), fetch=False)
+            else:
+                ox, oy = tiles.overview_offsets(lv, prev_lv)
+                eng.tiles_overview_u8((prev_lv.ny, prev_lv.nx), ox, oy, lv.nx, lv.ny, on_device=True, fetch=False)
+            t1 = time.perf_counter()
+            paths = [f"{output_dir}/{lv.zoom}/{lv.tminx + i}/{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png" for j in range(lv.ny) for i in range(lv.nx)]
+            eng.tiles_write_png(lv.nx, lv.ny, paths)              # tiles outside the raster (alpha 0 everywhere) get no file
+            prev_lv = lv
+            t_dev += t1 - t0
+            t_png += time.perf_counter() - t1
+    LAST_STATS.update(pyramid_level_kernels=t_dev, pyramid_png_on_device_and_files=t_png)
 
 
 def generate_xyz_tiles(input_path: Path, output_dir: Path, min_zoom: int = 10, max_zoom: int = 16, tile_size: int = 256,

@@ -7,10 +7,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
 
+#include "png_internal.h"
 #include "s2sr_internal.h"
 
 using namespace s2sr;
@@ -1733,7 +1736,7 @@ int s2sr_warp_bilinear_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t
 
 int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W, const int32_t* col_lo, const int32_t* col_hi,
                        const int32_t* row_lo, const int32_t* row_hi, int32_t nx, int32_t ny, uint8_t* out) {
-    if (!h || !rgba || !col_lo || !col_hi || !row_lo || !row_hi || !out || H <= 0 || W <= 0 || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
+    if (!h || !rgba || !col_lo || !col_hi || !row_lo || !row_hi || H <= 0 || W <= 0 || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
     for (int i = 0; i < nx * 256; ++i)
         if (col_lo[i] < 0 || col_hi[i] >= W) return fail(h, S2SR_E_INVALID, "column footprint table leaves the raster");
     for (int i = 0; i < ny * 256; ++i)
@@ -1757,7 +1760,7 @@ int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W
         HIPCHK(h, launch_tiles_base((const uint8_t*)h->d_scratch[0], W, t, t + nx * 256, t + 2 * nx * 256, t + 2 * nx * 256 + ny * 256, nx,
                                     ny, (uint8_t*)h->d_scratch[1], st));
     }
-    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
+    if (out) HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));      // out == NULL: the level stays on the device
     HIPCHK(h, hipStreamSynchronize(st));
     h->tiles_slot = 1; h->tiles_nx = nx; h->tiles_ny = ny;
     return S2SR_OK;
@@ -1765,7 +1768,7 @@ int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W
 
 int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, int32_t cny, int32_t ox, int32_t oy, int32_t pnx,
                            int32_t pny, uint8_t* out) {
-    if (!h || !out || cnx <= 0 || cny <= 0 || pnx <= 0 || pny <= 0) return S2SR_E_INVALID;
+    if (!h || cnx <= 0 || cny <= 0 || pnx <= 0 || pny <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
@@ -1787,9 +1790,127 @@ int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, in
         Scope sc(h, st, F_MISC, 0.0, (double)ib + (double)ob);
         HIPCHK(h, launch_tiles_overview((const uint8_t*)h->d_scratch[in_slot], cnx, cny, ox, oy, pnx, pny, (uint8_t*)h->d_scratch[out_slot], st));
     }
-    HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[out_slot], ob, hipMemcpyDeviceToHost, st));
+    if (out) HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[out_slot], ob, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     h->tiles_slot = out_slot; h->tiles_nx = pnx; h->tiles_ny = pny;
+    return S2SR_OK;
+}
+
+// The PNG files of the tile level the previous base / overview call left on the device: token statistics on the device, Huffman
+// codes on the host, bit emission on the device, chunk framing + CRC + file writes on host threads (pngdev.hip).  Only the
+// compressed streams cross PCIe.
+int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t skip_transparent, int32_t* written) {
+    if (!h || !paths || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->tiles_slot < 0 || h->tiles_nx != nx || h->tiles_ny != ny)
+        return fail(h, S2SR_E_INVALID, "the previous call on this handle did not leave a tile level of this size on the device");
+    const int slot = h->tiles_slot;
+    const uint8_t* d_tiles = (const uint8_t*)h->d_scratch[slot];
+    const int n = nx * ny;
+    hipStream_t st = h->stream;
+    const bool timing = getenv("S2SR_PNG_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double T[8] = {now()};
+    const size_t hist_b = (size_t)n * 512 * 4, adl_b = (size_t)n * 256 * 2 * 4, flag_b = (size_t)n * 4;
+    int rc;
+    if ((rc = ensure_scratch(h, 2, hist_b + adl_b + flag_b))) return rc;
+    uint32_t* d_hist = (uint32_t*)h->d_scratch[2];
+    uint32_t* d_adl = d_hist + (size_t)n * 512;
+    uint32_t* d_flag = d_adl + (size_t)n * 512;
+    HIPCHK(h, launch_png_tile_stats(d_tiles, n, d_hist, d_adl, d_flag, st));
+    std::vector<uint32_t> stats((hist_b + adl_b + flag_b) / 4);
+    HIPCHK(h, hipMemcpyAsync(stats.data(), d_hist, hist_b + adl_b + flag_b, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    T[1] = now();
+    PngTilePlan plan;
+    const size_t out_words = png_plan_tiles(n, stats.data(), stats.data() + (size_t)n * 512, stats.data() + (size_t)n * 1024, paths,
+                                            skip_transparent != 0, &plan);
+    T[2] = now();
+    const size_t tb_b = plan.tb.size() * 4, hdr_b = plan.hdr.size() * 4, meta_b = plan.meta.size();
+    if ((rc = ensure_scratch(h, 3, tb_b + hdr_b + meta_b))) return rc;
+    if ((rc = ensure_scratch(h, 4, (out_words + 1) * 4))) return rc;
+    uint8_t* d_tb = (uint8_t*)h->d_scratch[3];
+    uint32_t* d_out = (uint32_t*)h->d_scratch[4];
+    HIPCHK(h, hipMemcpyAsync(d_tb, plan.tb.data(), tb_b, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_tb + tb_b, plan.hdr.data(), hdr_b, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_tb + tb_b + hdr_b, plan.meta.data(), meta_b, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(d_out, 0, (out_words + 1) * 4, st));
+    HIPCHK(h, launch_png_tile_emit(d_tiles, n, d_tb + tb_b + hdr_b, (const uint32_t*)d_tb, (const uint32_t*)(d_tb + tb_b), d_out, st));
+    if (timing) { HIPCHK(h, hipStreamSynchronize(st)); }
+    T[3] = now();
+    // the few tiles that go to the host encoder (noise: stored blocks are smaller than a Huffman block) need their pixels
+    std::vector<int> host_tiles;
+    for (int t = 0; t < n; ++t) if (plan.mode[t] == 2) host_tiles.push_back(t);
+    std::vector<uint8_t> host_px(host_tiles.size() * (size_t)262144);
+    for (size_t k = 0; k < host_tiles.size(); ++k)
+        HIPCHK(h, hipMemcpyAsync(host_px.data() + k * 262144, d_tiles + (size_t)host_tiles[k] * 262144, 262144, hipMemcpyDeviceToHost, st));
+    // The compressed streams come back in batches of whole tiles through the two page-locked staging buffers: while one batch is
+    // framed, checksummed and written from its buffer by the host threads, the next one is on the wire.
+    for (int i = 0; i < 2; ++i) {
+        if (!h->stage_buf[i]) HIPCHK(h, host_malloc(&h->stage_buf[i], kStageBytes, hipHostMallocDefault));
+        if (!h->stage_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+    }
+    struct Batch { int t0, t1; size_t w0, w1; };
+    std::vector<Batch> batches;
+    {
+        const size_t cap_words = kStageBytes / 4;
+        int t0 = 0;
+        while (t0 < n) {
+            int t1 = t0;
+            const size_t w0 = plan.out_word[t0];
+            auto end_of = [&](int t) { return t + 1 < n ? plan.out_word[t + 1] : out_words; };
+            while (t1 < n && end_of(t1) - w0 <= cap_words) ++t1;
+            if (t1 == t0) return fail(h, S2SR_E_CAPACITY, "a tile's stream is larger than a staging buffer");
+            batches.push_back(Batch{t0, t1, w0, end_of(t1 - 1)});
+            t0 = t1;
+        }
+    }
+    std::atomic<int> failed{0};
+    if (written) for (int t = 0; t < n; ++t) written[t] = 0;
+    HIPCHK(h, hipStreamSynchronize(st));             // the emit kernel is done: the copy stream may read its output
+    for (size_t k = 0; k <= batches.size(); ++k) {
+        if (k < batches.size() && batches[k].w1 > batches[k].w0) {
+            HIPCHK(h, hipMemcpyAsync(h->stage_buf[k & 1], d_out + batches[k].w0, (batches[k].w1 - batches[k].w0) * 4, hipMemcpyDeviceToHost,
+                                     h->copy_stream));
+        }
+        if (k < batches.size()) HIPCHK(h, hipEventRecord(h->stage_ev[k & 1], h->copy_stream));
+        if (k > 0) {
+            const Batch& b = batches[k - 1];
+            HIPCHK(h, hipEventSynchronize(h->stage_ev[(k - 1) & 1]));
+            const uint32_t* words = (const uint32_t*)h->stage_buf[(k - 1) & 1];
+            png_parallel_for(b.t1 - b.t0, [&](int i) {
+                const int t = b.t0 + i;
+                if (plan.mode[t] != 1) return;
+                static thread_local std::vector<uint8_t> buf;
+                if (!png_write_tile_file(paths[t], words + (plan.out_word[t] - b.w0), plan.deflate_bytes[t], plan.eob[t], plan.eob_at[t],
+                                         plan.adler[t], buf))
+                    failed.store(1);
+                else if (written) written[t] = 1;
+            });
+        }
+    }
+    T[4] = now();
+    if (!host_tiles.empty()) {
+        const size_t cap = s2sr_png_bound(256, 256, 4);
+        png_parallel_for((int)host_tiles.size(), [&](int k) {
+            static thread_local std::vector<uint8_t> buf;
+            buf.resize(cap);
+            size_t len = 0;
+            const int t = host_tiles[k];
+            if (s2sr_png_encode(host_px.data() + (size_t)k * 262144, 256, 256, 4, 1024, buf.data(), cap, &len) != S2SR_OK ||
+                !png::write_file(paths[t], buf.data(), len))
+                failed.store(1);
+            else if (written) written[t] = 1;
+        });
+    }
+    T[5] = now();
+    if (timing)
+        fprintf(stderr, "[s2sr png] %d tiles (%zu on the host encoder): stats kernel + copy %.1f ms, plan %.1f, upload + emit kernel %.1f, "
+                "streams (%.0f MB) back in batches + files %.1f, host-encoded tiles %.1f\n", n, host_tiles.size(), T[1] - T[0], T[2] - T[1],
+                T[3] - T[2], (double)out_words * 4 / 1e6, T[4] - T[3], T[5] - T[4]);
+    h->tiles_slot = slot; h->tiles_nx = nx; h->tiles_ny = ny;      // the scratch requests above dropped the marker; the level is intact
+    if (failed.load()) return fail(h, S2SR_E_IO, "a tile file could not be written");
     return S2SR_OK;
 }
 

@@ -1,0 +1,283 @@
+// PNG encoding of a tile level ON THE DEVICE (the XYZ pyramid of a job is 12.8k RGBA tiles = 3.3 GB of pixels; fetching them to
+// deflate them on 16 host CPUs was the whole cost of the stage: 0.2 s of copies + 0.3 s of encoders).  The level stays where the
+// pyramid kernels left it; what crosses PCIe is the compressed stream (~70 KB per tile instead of 256 KB).
+//
+//   stats kernel   one workgroup per tile, one thread per row: the row's byte stream (filter byte 1, 1024 Sub-filtered bytes) is
+//                  walked once -- distance-1 runs inside the row become matches, the rest literals (the host encoder's token
+//                  alphabet, png_internal.h) -- into a per-tile token histogram (LDS, one table per wave), the row's Adler-32
+//                  partial sums and the tile's "any alpha" flag.
+//   host           per tile: Huffman code + block header from the histogram (build_block_code, the host encoder's own), the exact
+//                  compressed size (so the output buffer is laid out exactly), Adler-32 from the row sums.  Tiles that stored
+//                  blocks would serve better (noise) go to the host encoder.
+//   emit kernel    same walk twice: bits per row -> exclusive scan -> every row ORs its bits into the stream at its offset.
+//   host           chunk framing, CRC-32, file write, on threads.
+// Integer / byte work, HBM- (in fact L2-) bound: a tile is read three times as 16-byte loads, each row by one lane.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "png_internal.h"
+#include "s2sr_internal.h"
+
+namespace s2sr {
+
+namespace {
+
+constexpr int kRow = 1024;          // bytes of pixels per tile row (256 RGBA pixels)
+constexpr int kRows = 256;
+
+// Walks one row's stream and hands every token to `tok(t)` and every stream byte to `byte(b)`.
+template <class TokFn, class ByteFn>
+__device__ __forceinline__ void walk_row(const uint8_t* __restrict__ row, TokFn&& tok, ByteFn&& byte) {
+    uint32_t prev = 1;              // the filter-type byte: Sub
+    int run = 0;                    // bytes equal to `prev` seen behind it and not yet emitted
+    tok(1u);
+    byte(1u);
+    uint32_t left = 0;              // the pixel to the left (Sub, bpp = 4)
+    for (int q = 0; q < kRow / 16; ++q) {
+        const uint4 v = ((const uint4*)row)[q];
+        const uint32_t px[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = px[k];
+            const uint32_t d = ((a | 0x80808080u) - (left & 0x7F7F7F7Fu)) ^ ((a ^ ~left) & 0x80808080u);   // four byte-wise a - left
+            left = a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = (d >> (8 * j)) & 0xFFu;
+                byte(b);
+                if (b == prev) {
+                    if (++run == 258) { tok(256u + 255u); run = 0; }
+                } else {
+                    if (run >= 3) tok(256u + (uint32_t)(run - 3));
+                    else for (int r = 0; r < run; ++r) tok(prev);
+                    run = 0;
+                    tok(b);
+                    prev = b;
+                }
+            }
+        }
+    }
+    if (run >= 3) tok(256u + (uint32_t)(run - 3));
+    else for (int r = 0; r < run; ++r) tok(prev);
+}
+
+__global__ void __launch_bounds__(256) png_tile_stats_kernel(const uint8_t* __restrict__ tiles, int ntiles, uint32_t* __restrict__ hist,
+                                                             uint32_t* __restrict__ adler, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t h[4][512];
+    __shared__ uint32_t any_alpha;
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    for (int i = threadIdx.x; i < 4 * 512; i += 256) (&h[0][0])[i] = 0;
+    if (threadIdx.x == 0) any_alpha = 0;
+    __syncthreads();
+    const uint8_t* row = tiles + ((size_t)t * kRows + threadIdx.x) * kRow;
+    uint32_t* hw = h[threadIdx.x >> 6];
+    uint32_t a = 0, b = 0, last = 0xFFFFFFFFu, cnt = 0, alpha = 0;
+    {   // alpha of the row (byte 3 of every pixel), before the filter
+        for (int q = 0; q < kRow / 16; ++q) {
+            const uint4 v = ((const uint4*)row)[q];
+            alpha |= (v.x | v.y | v.z | v.w) >> 24;
+        }
+    }
+    walk_row(row,
+             [&](uint32_t tk) {
+                 if (tk == last) { ++cnt; return; }
+                 if (cnt) atomicAdd(&hw[last], cnt);
+                 last = tk;
+                 cnt = 1;
+             },
+             [&](uint32_t by) { a += by; b += a; });
+    if (cnt) atomicAdd(&hw[last], cnt);
+    if (alpha) atomicOr(&any_alpha, 1u);
+    adler[((size_t)t * kRows + threadIdx.x) * 2] = a;
+    adler[((size_t)t * kRows + threadIdx.x) * 2 + 1] = b;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) hist[(size_t)t * 512 + i] = h[0][i] + h[1][i] + h[2][i] + h[3][i];
+    if (threadIdx.x == 0) flags[t] = any_alpha;
+}
+
+struct TileMeta {
+    uint64_t out_word;      // first 32-bit word of the tile's region in the output buffer
+    uint32_t header_bits;   // block header bits in front of the rows' bits
+    uint32_t skip;          // nothing to emit for this tile
+};
+
+__global__ void __launch_bounds__(256) png_tile_emit_kernel(const uint8_t* __restrict__ tiles, int ntiles, const TileMeta* __restrict__ meta,
+                                                            const uint32_t* __restrict__ tbs, const uint32_t* __restrict__ hdrs,
+                                                            uint32_t* __restrict__ out) {
+    __shared__ uint32_t tb[512];
+    __shared__ uint32_t row_bits[kRows];
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    const TileMeta m = meta[t];
+    if (m.skip) return;
+    for (int i = threadIdx.x; i < 512; i += 256) tb[i] = tbs[(size_t)t * 512 + i];
+    __syncthreads();
+    const uint8_t* row = tiles + ((size_t)t * kRows + threadIdx.x) * kRow;
+    uint32_t bits = 0;
+    walk_row(row, [&](uint32_t tk) { bits += tb[tk] >> 24; }, [](uint32_t) {});
+    row_bits[threadIdx.x] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {                          // exclusive scan of 256 values: not worth more than this
+        uint32_t acc = m.header_bits;
+        for (int r = 0; r < kRows; ++r) { const uint32_t v = row_bits[r]; row_bits[r] = acc; acc += v; }
+    }
+    __syncthreads();
+    uint32_t* o = out + m.out_word;
+    // block header: whole words, the last one partial (zero above header_bits)
+    for (uint32_t w = threadIdx.x; w * 32 < m.header_bits; w += 256) atomicOr(&o[w], hdrs[(size_t)t * 160 + w]);
+    // this row's bits
+    uint32_t at = row_bits[threadIdx.x];
+    uint32_t w = at >> 5;
+    uint64_t acc = 0;
+    int n = (int)(at & 31u);
+    walk_row(row,
+             [&](uint32_t tk) {
+                 const uint32_t e = tb[tk];
+                 acc |= (uint64_t)(e & 0xFFFFFFu) << n;
+                 n += (int)(e >> 24);
+                 if (n >= 32) { atomicOr(&o[w++], (uint32_t)acc); acc >>= 32; n -= 32; }
+             },
+             [](uint32_t) {});
+    if (n > 0) atomicOr(&o[w], (uint32_t)acc);
+}
+
+int host_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 4;
+    if (const char* e = getenv("S2SR_HOST_THREADS")) { const int v = atoi(e); if (v > 0 && v < n) n = v; }
+    else if (n > 32) n = 32;
+    return n;
+}
+
+template <class F> void parallel_for(int n, F&& body) {      // body(i) for i in [0, n), dynamic chunks of 16
+    const int nt = std::min(host_threads(), (n + 15) / 16);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i0 = next.fetch_add(16);
+            if (i0 >= n) return;
+            for (int i = i0; i < std::min(n, i0 + 16); ++i) body(i);
+        }
+    };
+    if (nt <= 1) { work(); return; }
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(png_tile_stats_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, d_hist, d_adler, d_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* d_meta, const uint32_t* d_tb, const uint32_t* d_hdr,
+                                uint32_t* d_out, hipStream_t st) {
+    if (ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(png_tile_emit_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, (const TileMeta*)d_meta, d_tb, d_hdr, d_out);
+    return hipGetLastError();
+}
+
+// ---- host side of the plan ---------------------------------------------------------------------
+// From the stats of `n` tiles: per tile the Huffman table / header / meta the emit kernel reads, the Adler-32 of the stream and the
+// size of its deflate bytes.  mode[t]: 0 = nothing to write (no path, or fully transparent), 1 = device stream, 2 = host encoder
+// (stored blocks would be smaller than this tile's Huffman block).  Returns the number of 32-bit words the output buffer needs.
+size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
+                      bool skip_transparent, PngTilePlan* plan) {
+    plan->mode.assign(n, 0);
+    plan->adler.assign(n, 0);
+    plan->deflate_bytes.assign(n, 0);
+    plan->eob.assign(n, 0);
+    plan->eob_at.assign(n, 0);
+    plan->tb.assign((size_t)n * 512, 0);
+    plan->hdr.assign((size_t)n * 160, 0);
+    plan->meta.assign((size_t)n * sizeof(TileMeta), 0);
+    std::vector<uint32_t> words(n, 0);
+    parallel_for(n, [&](int t) {
+        TileMeta* m = (TileMeta*)plan->meta.data() + t;
+        m->skip = 1;
+        if (!paths[t] || (skip_transparent && !flags[t])) return;
+        png::BlockCode bc;
+        png::build_block_code(hist + (size_t)t * 512, true, &bc);
+        const uint64_t bits = bc.header_bits + bc.body_bits;
+        const size_t nraw = (size_t)kRows * (kRow + 1);
+        if (bits >= 8 * (uint64_t)nraw + 40 * ((nraw + 65534) / 65535) || bc.header_bits > 160 * 32) { plan->mode[t] = 2; return; }
+        plan->mode[t] = 1;
+        m->skip = 0;
+        m->header_bits = bc.header_bits;
+        memcpy(&plan->tb[(size_t)t * 512], bc.tb, sizeof bc.tb);
+        memcpy(&plan->hdr[(size_t)t * 160], bc.header, (bc.header_bits + 7) / 8);
+        // the end-of-block code is the last thing in the stream: the host ORs it in after the copy back (its offset is known here)
+        plan->eob[t] = bc.eob;
+        plan->eob_at[t] = bits - (bc.eob >> 24);
+        uint32_t a = 1, b = 0;      // Adler-32 over the 256 rows from their partial sums (a row of len bytes adds len * a + B to b)
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t A = adler_rows[((size_t)t * kRows + r) * 2], B = adler_rows[((size_t)t * kRows + r) * 2 + 1];
+            b = (uint32_t)((b + (uint64_t)(kRow + 1) * a + B) % 65521u);
+            a = (uint32_t)((a + (uint64_t)A) % 65521u);
+        }
+        plan->adler[t] = (b << 16) | a;
+        plan->deflate_bytes[t] = (uint32_t)((bits + 7) / 8);
+        words[t] = (uint32_t)((bits + 31) / 32 + 1);
+    });
+    size_t total = 0;
+    for (int t = 0; t < n; ++t) {
+        TileMeta* m = (TileMeta*)plan->meta.data() + t;
+        m->out_word = total;
+        total += words[t];
+    }
+    plan->out_word.resize(n);
+    for (int t = 0; t < n; ++t) plan->out_word[t] = ((const TileMeta*)plan->meta.data() + t)->out_word;
+    return total;
+}
+
+// One tile's file from its deflate bytes (end-of-block code not yet in): PNG signature, IHDR 256 x 256 RGBA, one IDAT, IEND.
+bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t deflate_bytes, uint32_t eob, uint64_t eob_at, uint32_t adler,
+                         std::vector<uint8_t>& buf) {
+    struct Head {
+        uint8_t b[33];
+        Head() {
+            static const uint8_t h[29] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n', 0, 0, 0, 13, 'I', 'H', 'D', 'R', 0, 0, 1, 0, 0, 0, 1, 0, 8, 6, 0, 0, 0};
+            memcpy(b, h, 29);
+            const uint32_t c = png::crc32_update(0, b + 12, 17);
+            b[29] = (uint8_t)(c >> 24); b[30] = (uint8_t)(c >> 16); b[31] = (uint8_t)(c >> 8); b[32] = (uint8_t)c;
+        }
+    };
+    static const Head H;
+    const uint8_t* head = H.b;
+    const size_t idat = 2 + (size_t)deflate_bytes + 4;
+    buf.resize(33 + 12 + idat + 12);
+    uint8_t* p = buf.data();
+    memcpy(p, head, 33);
+    p += 33;
+    p[0] = (uint8_t)(idat >> 24); p[1] = (uint8_t)(idat >> 16); p[2] = (uint8_t)(idat >> 8); p[3] = (uint8_t)idat;
+    memcpy(p + 4, "IDAT", 4);
+    p[8] = 0x78; p[9] = 0x01;
+    uint8_t* d = p + 10;
+    memcpy(d, words, deflate_bytes);
+    {   // the end-of-block code, LSB first at bit eob_at
+        uint64_t v = (uint64_t)(eob & 0xFFFFFFu) << (eob_at & 7);
+        for (size_t k = eob_at >> 3; v; ++k, v >>= 8) d[k] |= (uint8_t)v;
+    }
+    uint8_t* tail = d + deflate_bytes;
+    tail[0] = (uint8_t)(adler >> 24); tail[1] = (uint8_t)(adler >> 16); tail[2] = (uint8_t)(adler >> 8); tail[3] = (uint8_t)adler;
+    const uint32_t crc = png::crc32_update(0, p + 4, 4 + idat);
+    tail[4] = (uint8_t)(crc >> 24); tail[5] = (uint8_t)(crc >> 16); tail[6] = (uint8_t)(crc >> 8); tail[7] = (uint8_t)crc;
+    static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82};
+    memcpy(tail + 8, iend, 12);
+    return png::write_file(path, buf.data(), buf.size());
+}
+
+void png_parallel_for(int n, const std::function<void(int)>& body) { parallel_for(n, body); }
+
+}  // namespace s2sr

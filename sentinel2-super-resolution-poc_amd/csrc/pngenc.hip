@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/s2sr.h"
+#include "png_internal.h"
 
 namespace {
 
@@ -38,7 +39,8 @@ const CrcTables& crc_tables() {
     static const CrcTables T;
     return T;
 }
-uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {      // slice-by-8; crc is the running value (not inverted)
+}  // namespace
+uint32_t s2sr::png::crc32_update(uint32_t crc, const uint8_t* p, size_t n) {      // slice-by-8; crc is the running value (not inverted)
     const CrcTables& T = crc_tables();
     uint32_t c = ~crc;
     while (n >= 8) {
@@ -54,7 +56,7 @@ uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {      // slice-
     while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
     return ~c;
 }
-uint32_t adler32_update(uint32_t adler, const uint8_t* p, size_t n) {
+uint32_t s2sr::png::adler32_update(uint32_t adler, const uint8_t* p, size_t n) {
     uint32_t a = adler & 0xFFFF;
     uint64_t b = adler >> 16;
     while (n) {
@@ -71,6 +73,9 @@ uint32_t adler32_update(uint32_t adler, const uint8_t* p, size_t n) {
     }
     return ((uint32_t)b << 16) | a;
 }
+
+namespace {
+using namespace s2sr::png;
 
 inline uint64_t load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
@@ -211,19 +216,13 @@ const LenSym& len_syms() {
     return L;
 }
 
-// One deflate block: tokens [t0, t1) covering raw[r0, r1).  Token: 0..255 literal, 256 + (len - 3) a distance-1 match.
-void emit_block(BitWriter& bw, const uint16_t* tok, size_t t0, size_t t1, const uint8_t* raw, size_t r0, size_t r1, bool final_block) {
+}  // namespace
+
+void s2sr::png::build_block_code(const uint32_t* tok_freq, bool final_block, BlockCode* bc) {
     const LenSym& LS = len_syms();
-    // token histogram over 512 slots (literals, then match lengths), four tables so that a repeated token does not wait for
-    // its own previous increment (filtered imagery is mostly 0x00 / 0x01 / 0xFF)
-    uint32_t h4[4][512];
-    memset(h4, 0, sizeof h4);
-    size_t hi = t0;
-    for (; hi + 4 <= t1; hi += 4) { ++h4[0][tok[hi]]; ++h4[1][tok[hi + 1]]; ++h4[2][tok[hi + 2]]; ++h4[3][tok[hi + 3]]; }
-    for (; hi < t1; ++hi) ++h4[0][tok[hi]];
     uint32_t freq[286] = {0};
-    for (int t = 0; t < 256; ++t) freq[t] = h4[0][t] + h4[1][t] + h4[2][t] + h4[3][t];
-    for (int t = 256; t < 512; ++t) freq[LS.sym[t - 256]] += h4[0][t] + h4[1][t] + h4[2][t] + h4[3][t];
+    for (int t = 0; t < 256; ++t) freq[t] = tok_freq[t];
+    for (int t = 256; t < 512; ++t) freq[LS.sym[t - 256]] += tok_freq[t];
     freq[256] = 1;
     uint8_t ll_len[286];
     uint16_t ll_code[286];
@@ -270,10 +269,54 @@ void emit_block(BitWriter& bw, const uint16_t* tok, size_t t0, size_t t1, const 
     huffman_codes(cl_len, 19, cl_code);
     int hclen = 19;
     while (hclen > 4 && !cl_len[kClOrder[hclen - 1]]) --hclen;
-    // cost against stored blocks
-    uint64_t bits = 3 + 5 + 5 + 4 + 3 * (uint64_t)hclen;
-    for (int i = 0; i < ncl; ++i) bits += cl_len[cl_sym[i]] + (cl_sym[i] == 16 ? 2 : cl_sym[i] == 17 ? 3 : cl_sym[i] == 18 ? 7 : 0);
-    for (int s = 0; s < 286; ++s) bits += (uint64_t)freq[s] * (ll_len[s] + (s > 256 ? kLenExtra[s - 257] + 1 : 0));
+    // the block header into bc->header (at most 17 + 57 + 287 * 14 bits)
+    memset(bc->header, 0, sizeof bc->header);
+    BitWriter hw;
+    hw.p = bc->header;
+    hw.end = bc->header + sizeof bc->header;
+    hw.put((final_block ? 1 : 0) | (2 << 1), 3);
+    hw.put(hlit - 257, 5);
+    hw.put(0, 5);                                    // HDIST - 1
+    hw.put(hclen - 4, 4);
+    for (int i = 0; i < hclen; ++i) hw.put(cl_len[kClOrder[i]], 3);
+    for (int i = 0; i < ncl; ++i) {
+        const int s = cl_sym[i];
+        hw.put(cl_code[s], cl_len[s]);
+        if (s == 16) hw.put(cl_extra[i], 2);
+        else if (s == 17) hw.put(cl_extra[i], 3);
+        else if (s == 18) hw.put(cl_extra[i], 7);
+    }
+    bc->header_bits = (uint32_t)((hw.p - bc->header) * 8 + hw.n);
+    hw.align();
+    // token -> (bits, count): a literal's code; a match's length code | extra bits | the 1-bit distance code 0
+    for (int i = 0; i < 256; ++i) bc->tb[i] = ll_code[i] | ((uint32_t)ll_len[i] << 24);
+    for (int l = 0; l < 256; ++l) {
+        const int sy = LS.sym[l];
+        if (!ll_len[sy]) { bc->tb[256 + l] = 0; continue; }
+        const int eb = kLenExtra[sy - 257];
+        bc->tb[256 + l] = (ll_code[sy] | ((uint32_t)((l + 3) - kLenBase[sy - 257]) << ll_len[sy])) | ((uint32_t)(ll_len[sy] + eb + 1) << 24);
+    }
+    bc->eob = ll_code[256] | ((uint32_t)ll_len[256] << 24);
+    uint64_t bits = ll_len[256];
+    for (int t = 0; t < 512; ++t) bits += (uint64_t)tok_freq[t] * (bc->tb[t] >> 24);
+    bc->body_bits = bits;
+}
+
+namespace {
+
+// One deflate block: tokens [t0, t1) covering raw[r0, r1).
+void emit_block(BitWriter& bw, const uint16_t* tok, size_t t0, size_t t1, const uint8_t* raw, size_t r0, size_t r1, bool final_block) {
+    // token histogram over 512 slots (literals, then match lengths), four tables so that a repeated token does not wait for
+    // its own previous increment (filtered imagery is mostly 0x00 / 0x01 / 0xFF)
+    uint32_t h4[4][512];
+    memset(h4, 0, sizeof h4);
+    size_t hi = t0;
+    for (; hi + 4 <= t1; hi += 4) { ++h4[0][tok[hi]]; ++h4[1][tok[hi + 1]]; ++h4[2][tok[hi + 2]]; ++h4[3][tok[hi + 3]]; }
+    for (; hi < t1; ++hi) ++h4[0][tok[hi]];
+    for (int t = 0; t < 512; ++t) h4[0][t] += h4[1][t] + h4[2][t] + h4[3][t];
+    BlockCode bc;
+    build_block_code(h4[0], final_block, &bc);
+    const uint64_t bits = bc.header_bits + bc.body_bits;
     const size_t nraw = r1 - r0;
     const uint64_t stored_bits = 8 * (uint64_t)nraw + 40 * ((nraw + 65534) / 65535 + (nraw == 0)) + 7;
     if (bits >= stored_bits) {
@@ -291,28 +334,9 @@ void emit_block(BitWriter& bw, const uint16_t* tok, size_t t0, size_t t1, const 
         return;
     }
     if ((uint64_t)(bw.end - bw.p) < bits / 8 + 32) { bw.ok = false; return; }
-    bw.put((final_block ? 1 : 0) | (2 << 1), 3);
-    bw.put(hlit - 257, 5);
-    bw.put(0, 5);                                    // HDIST - 1
-    bw.put(hclen - 4, 4);
-    for (int i = 0; i < hclen; ++i) bw.put(cl_len[kClOrder[i]], 3);
-    for (int i = 0; i < ncl; ++i) {
-        const int s = cl_sym[i];
-        bw.put(cl_code[s], cl_len[s]);
-        if (s == 16) bw.put(cl_extra[i], 2);
-        else if (s == 17) bw.put(cl_extra[i], 3);
-        else if (s == 18) bw.put(cl_extra[i], 7);
-    }
-    // per block: token -> (bits, count) in one table: a literal's code; a match's length code | extra bits | the 1-bit distance
-    // code 0.  Two tokens per step through the byte-granular writer (<= 42 bits on top of <= 7 pending).
-    uint32_t tb[512];
-    for (int i = 0; i < 256; ++i) tb[i] = ll_code[i] | ((uint32_t)ll_len[i] << 24);
-    for (int l = 0; l < 256; ++l) {
-        const int sy = LS.sym[l];
-        if (!ll_len[sy]) { tb[256 + l] = 0; continue; }
-        const int eb = kLenExtra[sy - 257];
-        tb[256 + l] = (ll_code[sy] | ((uint32_t)((l + 3) - kLenBase[sy - 257]) << ll_len[sy])) | ((uint32_t)(ll_len[sy] + eb + 1) << 24);
-    }
+    for (uint32_t k = 0; k < bc.header_bits; k += 8) bw.put(bc.header[k >> 3], bc.header_bits - k < 8 ? (int)(bc.header_bits - k) : 8);
+    // two tokens per step through the byte-granular writer (<= 42 bits on top of <= 7 pending)
+    const uint32_t* tb = bc.tb;
     bw.fast_begin();
     size_t i = t0;
     for (; i + 2 <= t1; i += 2) {
@@ -322,7 +346,7 @@ void emit_block(BitWriter& bw, const uint16_t* tok, size_t t0, size_t t1, const 
     }
     if (i < t1) bw.fast_put(tb[tok[i]] & 0xFFFFFF, (int)(tb[tok[i]] >> 24));
     bw.fast_end();
-    bw.put(ll_code[256], ll_len[256]);
+    bw.put(bc.eob & 0xFFFFFF, (int)(bc.eob >> 24));
 }
 
 // Sub-filter `rows` rows of c-byte pixels into raw (rows x (1 + w*c)), tokenise, emit deflate blocks.  `finish`: the last block
@@ -508,9 +532,7 @@ extern "C" int s2sr_png_idat_band(const uint8_t* px, int32_t width, int32_t rows
     return S2SR_OK;
 }
 
-namespace {
-
-bool write_file(const char* path, const uint8_t* data, size_t n) {
+bool s2sr::png::write_file(const char* path, const uint8_t* data, size_t n) {
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd < 0 && errno == ENOENT) {                 // z/x/ does not exist yet: make the missing directories, once
         std::string p(path);
@@ -535,8 +557,6 @@ bool write_file(const char* path, const uint8_t* data, size_t n) {
     }
     return close(fd) == 0;
 }
-
-}  // namespace
 
 extern "C" int s2sr_png_write_tiles(const uint8_t* tiles, int32_t count, int32_t size, int32_t channels, size_t tile_stride,
                                     const char* const* paths, int32_t skip_transparent, int32_t* written) {

@@ -4,7 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <functional>
 #include <mutex>
+#include <vector>
 
 #include "../../include/s2sr.h"
 
@@ -222,6 +224,23 @@ hipError_t launch_tiles_base(const uint8_t* d_rgba, int W, const int32_t* d_col_
                              const int32_t* d_row_hi, int nx, int ny, uint8_t* d_out, hipStream_t st);
 hipError_t launch_tiles_overview(const uint8_t* d_child, int cnx, int cny, int ox, int oy, int pnx, int pny, uint8_t* d_out,
                                  hipStream_t st);
+
+// PNG encoding of a tile level on the device (pngdev.hip): stats kernel -> host plan (Huffman codes, sizes) -> emit kernel.
+struct PngTilePlan {
+    std::vector<uint8_t> mode;            // 0 nothing to write, 1 device stream, 2 host encoder (stored blocks are smaller)
+    std::vector<uint32_t> adler, deflate_bytes, eob;
+    std::vector<uint64_t> eob_at, out_word;
+    std::vector<uint32_t> tb, hdr;        // [n][512] token table, [n][160] block header words (what the emit kernel reads)
+    std::vector<uint8_t> meta;            // [n] TileMeta (pngdev.hip)
+};
+hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, hipStream_t st);
+hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* d_meta, const uint32_t* d_tb, const uint32_t* d_hdr,
+                                uint32_t* d_out, hipStream_t st);
+size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
+                      bool skip_transparent, PngTilePlan* plan);
+bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t deflate_bytes, uint32_t eob, uint64_t eob_at, uint32_t adler,
+                         std::vector<uint8_t>& buf);
+void png_parallel_for(int n, const std::function<void(int)>& body);
 
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);

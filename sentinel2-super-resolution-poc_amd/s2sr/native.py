@@ -109,6 +109,7 @@ _PROTOS = {
                                         C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_base_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_overview_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
+    "s2sr_tiles_write_png": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_tiff_lzw_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_png_bound": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -576,27 +577,43 @@ class Engine:
                                                     grid.shape[1], step, out_h, out_w, _ptr(out)), "s2sr_warp_bilinear_u8")
         return out
 
-    def tiles_base_u8(self, rgba: np.ndarray, col_lo, col_hi, row_lo, row_hi) -> np.ndarray:
+    def tiles_base_u8(self, rgba: np.ndarray, col_lo, col_hi, row_lo, row_hi, fetch: bool = True) -> Optional[np.ndarray]:
+        """fetch=False: the level is computed and left on the device (for tiles_write_png / the next overview); returns None."""
         rgba = np.ascontiguousarray(rgba, np.uint8)
         t = [np.ascontiguousarray(a, np.int32) for a in (col_lo, col_hi, row_lo, row_hi)]
         nx, ny = t[0].size // 256, t[2].size // 256
-        out = np.empty((ny, nx, 256, 256, 4), np.uint8)
+        out = np.empty((ny, nx, 256, 256, 4), np.uint8) if fetch else None
         self._check(self._lib.s2sr_tiles_base_u8(self._h, _ptr(rgba), rgba.shape[0], rgba.shape[1], _ptr(t[0]), _ptr(t[1]), _ptr(t[2]),
-                                                 _ptr(t[3]), nx, ny, _ptr(out)), "s2sr_tiles_base_u8")
+                                                 _ptr(t[3]), nx, ny, _ptr(out) if fetch else None), "s2sr_tiles_base_u8")
         return out
 
-    def tiles_overview_u8(self, child: np.ndarray, ox: int, oy: int, pnx: int, pny: int, on_device: bool = False) -> np.ndarray:
-        """on_device: `child` is the array the previous tiles_base_u8 / tiles_overview_u8 call on this engine returned and nothing
-        else ran on the engine since: its device copy is used instead of uploading it again (only its shape is read)."""
-        out = np.empty((pny, pnx, 256, 256, 4), np.uint8)
+    def tiles_overview_u8(self, child, ox: int, oy: int, pnx: int, pny: int, on_device: bool = False,
+                          fetch: bool = True) -> Optional[np.ndarray]:
+        """on_device: the children are the level the previous tiles_base_u8 / tiles_overview_u8 call on this engine produced and
+        nothing else ran on the engine since: its device copy is used instead of an upload; `child` is then only read for its
+        shape (the array, or a (cny, cnx) pair).  fetch=False: the new level stays on the device, returns None."""
+        out = np.empty((pny, pnx, 256, 256, 4), np.uint8) if fetch else None
         if on_device:
+            cny, cnx = child.shape[:2] if hasattr(child, "shape") else child
             src = None
         else:
             child = np.ascontiguousarray(child, np.uint8)
+            cny, cnx = child.shape[:2]
             src = _ptr(child)
-        self._check(self._lib.s2sr_tiles_overview_u8(self._h, src, child.shape[1], child.shape[0], ox, oy, pnx, pny, _ptr(out)),
+        self._check(self._lib.s2sr_tiles_overview_u8(self._h, src, cnx, cny, ox, oy, pnx, pny, _ptr(out) if fetch else None),
                     "s2sr_tiles_overview_u8")
         return out
+
+    def tiles_write_png(self, nx: int, ny: int, paths, skip_transparent: bool = True) -> np.ndarray:
+        """The PNG files of the level the previous tiles call left on the device, encoded there (s2sr_tiles_write_png): `paths` has
+        ny * nx entries in the tile array's order (None = skip).  Returns the 0/1 array [ny, nx] of files written."""
+        if len(paths) != nx * ny:
+            raise ValueError(f"{nx * ny} tiles, {len(paths)} paths")
+        cp = (C.c_char_p * (nx * ny))(*[None if p is None else os.fsencode(p) for p in paths])
+        written = np.zeros(nx * ny, np.int32)
+        self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent), written.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "s2sr_tiles_write_png")
+        return written.reshape(ny, nx)
 
     def synchronize(self):
         self._check(self._lib.s2sr_synchronize(self._h), "s2sr_synchronize")

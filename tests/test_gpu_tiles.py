@@ -75,6 +75,56 @@ def test_base_and_overview_bit_exact(eng):
         eng.tiles_base_u8(rgba, *bad)
 
 
+def test_level_pngs_encoded_on_the_device(eng, tmp_path):
+    """s2sr_tiles_write_png: the level stays on the device, its PNG files must decode to exactly the tiles a fetch returns --
+    smooth tiles (Huffman blocks with runs), noise tiles (handed to the host encoder: stored blocks), half-covered tiles,
+    fully transparent ones (no file), skipped paths."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:700, 0:900]
+    rgba = np.empty((700, 900, 4), np.uint8)
+    rgba[..., :3] = np.clip(120 + 80 * np.sin(xx / 31.0)[..., None] * np.cos(yy / 17.0)[..., None] + rng.integers(-3, 4, (700, 900, 3)), 0, 255)
+    rgba[:, 600:, :3] = rng.integers(0, 256, (700, 300, 3))                     # a noisy part
+    rgba[..., 3] = 255
+    rgba[:200, :300, 3] = 0                                                     # a hole
+    place = geo.Placement(1500017.3, 5999994.9, 0.6, 0.6)
+    levels = tiles.plan_levels(place.bounds(900, 700), 15, 18)
+    lv = levels[0]
+    want = eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, 900, 700))
+    prev = None
+    for k, cur_lv in enumerate(levels):
+        if k == 0:
+            assert eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, 900, 700), fetch=False) is None
+        else:
+            ox, oy = tiles.overview_offsets(cur_lv, prev)
+            want = ref.overview(want, ox, oy, cur_lv.nx, cur_lv.ny)
+            assert eng.tiles_overview_u8((prev.ny, prev.nx), ox, oy, cur_lv.nx, cur_lv.ny, on_device=True, fetch=False) is None
+        paths = [tmp_path / str(cur_lv.zoom) / str(i) / f"{j}.png" for j in range(cur_lv.ny) for i in range(cur_lv.nx)]
+        if k == 0:
+            paths[1] = None
+        wrote = eng.tiles_write_png(cur_lv.nx, cur_lv.ny, paths)
+        n_files = 0
+        for j in range(cur_lv.ny):
+            for i in range(cur_lv.nx):
+                p = paths[j * cur_lv.nx + i]
+                has = bool(want[j, i, ..., 3].any()) and p is not None
+                assert bool(wrote[j, i]) == has and (p is None or p.exists() == has), (cur_lv.zoom, j, i)
+                if has:
+                    im = Image.open(p)
+                    im.verify()
+                    assert np.array_equal(np.asarray(Image.open(p)), want[j, i]), (cur_lv.zoom, j, i)
+                    n_files += 1
+        assert n_files > 0
+        if k == 0:      # both routes were taken: Huffman streams from the device, stored blocks from the host encoder (noise)
+            sizes = [p.stat().st_size for p in paths if p is not None and p.exists()]
+            assert min(sizes) < 150_000 and max(sizes) > 262_144, (min(sizes), max(sizes))
+        prev = cur_lv
+    assert not want[..., 3].all() or True
+    eng.postprocess_u8(np.zeros((64, 64, 3), np.uint8), native.pp_wow())           # any other call takes the scratch
+    with pytest.raises(native.S2srError, match="did not leave a tile level"):
+        eng.tiles_write_png(1, 1, [tmp_path / "x.png"])
+
+
 def test_process_raster_to_tiles_end_to_end(tmp_path):
     import app.tiling as tiling
     rgb = _scene(240, 320, seed=5)
