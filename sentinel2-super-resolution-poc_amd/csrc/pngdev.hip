@@ -203,6 +203,8 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     plan->hdr.assign((size_t)n * 160, 0);
     plan->meta.assign((size_t)n * sizeof(TileMeta), 0);
     std::vector<uint32_t> words(n, 0);
+    const char* fh = getenv("S2SR_PNG_FORCE_HOST");      // diagnostic: every tile through the host encoder (the route of incompressible tiles)
+    const bool force_host = fh && atoi(fh) != 0;
     parallel_for(n, [&](int t) {
         TileMeta* m = (TileMeta*)plan->meta.data() + t;
         m->skip = 1;
@@ -211,7 +213,7 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
         png::build_block_code(hist + (size_t)t * 512, true, &bc);
         const uint64_t bits = bc.header_bits + bc.body_bits;
         const size_t nraw = (size_t)kRows * (kRow + 1);
-        if (bits >= 8 * (uint64_t)nraw + 40 * ((nraw + 65534) / 65535) || bc.header_bits > 160 * 32) { plan->mode[t] = 2; return; }
+        if (bits >= 8 * (uint64_t)nraw + 40 * ((nraw + 65534) / 65535) || bc.header_bits > 160 * 32 || force_host) { plan->mode[t] = 2; return; }
         plan->mode[t] = 1;
         m->skip = 0;
         m->header_bits = bc.header_bits;

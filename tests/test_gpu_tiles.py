@@ -75,7 +75,7 @@ def test_base_and_overview_bit_exact(eng):
         eng.tiles_base_u8(rgba, *bad)
 
 
-def test_level_pngs_encoded_on_the_device(eng, tmp_path):
+def test_level_pngs_encoded_on_the_device(eng, tmp_path, monkeypatch):
     """s2sr_tiles_write_png: the level stays on the device, its PNG files must decode to exactly the tiles a fetch returns --
     smooth tiles (Huffman blocks with runs), noise tiles (handed to the host encoder: stored blocks), half-covered tiles,
     fully transparent ones (no file), skipped paths."""
@@ -115,11 +115,29 @@ def test_level_pngs_encoded_on_the_device(eng, tmp_path):
                     assert np.array_equal(np.asarray(Image.open(p)), want[j, i]), (cur_lv.zoom, j, i)
                     n_files += 1
         assert n_files > 0
-        if k == 0:      # both routes were taken: Huffman streams from the device, stored blocks from the host encoder (noise)
-            sizes = [p.stat().st_size for p in paths if p is not None and p.exists()]
-            assert min(sizes) < 150_000 and max(sizes) > 262_144, (min(sizes), max(sizes))
+        if k == 0:      # Huffman streams from the device: a smooth tile is a fraction of its 256 KB
+            assert min(p.stat().st_size for p in paths if p is not None and p.exists()) < 150_000
         prev = cur_lv
     assert not want[..., 3].all() or True
+    # A level made of the raster's own pixels (footprint tables of one pixel each): noise, a flat and a transparent tile.  Level
+    # alpha is 0 or 255, so even noise keeps a compressible channel and stays on the device route; the host-encoder route (taken
+    # when stored blocks would be smaller, or a block header outgrows its slot) is forced once through its diagnostic switch.
+    noise = rng.integers(0, 256, (512, 512, 4), dtype=np.uint8)
+    noise[..., 3] = 255
+    noise[256:, :256, :3] = 77
+    noise[256:, 256:, 3] = 0
+    ident = np.arange(512, dtype=np.int32)
+    got = eng.tiles_base_u8(noise, ident, ident, ident, ident)
+    assert np.array_equal(got[1, 0], noise[256:, :256]) and np.array_equal(got[0, 1], noise[:256, 256:])
+    for force_host in ("0", "1"):
+        monkeypatch.setenv("S2SR_PNG_FORCE_HOST", force_host)
+        eng.tiles_base_u8(noise, ident, ident, ident, ident, fetch=False)
+        npaths = [tmp_path / f"noise{force_host}" / f"{j}_{i}.png" for j in range(2) for i in range(2)]
+        assert eng.tiles_write_png(2, 2, npaths).tolist() == [[1, 1], [1, 0]]
+        for q, (j, i) in zip(npaths[:3], ((0, 0), (0, 1), (1, 0))):
+            assert np.array_equal(np.asarray(Image.open(q)), got[j, i]), (force_host, j, i)
+        assert npaths[2].stat().st_size < 2_000 and not npaths[3].exists()
+    monkeypatch.delenv("S2SR_PNG_FORCE_HOST")
     eng.postprocess_u8(np.zeros((64, 64, 3), np.uint8), native.pp_wow())           # any other call takes the scratch
     with pytest.raises(native.S2srError, match="did not leave a tile level"):
         eng.tiles_write_png(1, 1, [tmp_path / "x.png"])

@@ -4,6 +4,7 @@ fixed time, as Starlette's pool does under load (reference main.py:247-368, 629-
 byte-identical to the first PNG produced for the same (input, options); device memory and host RSS settle after the first round of
 every shape.  Usage: tools/soak_jobs.py [seconds=120] [threads=4]"""
 import hashlib
+import shutil
 import os
 import sys
 import tempfile
@@ -40,6 +41,7 @@ for i, (h, w) in enumerate([(256, 256), (300, 421), (512, 512), (97, 640), (700,
     rio.write_geotiff_rgb(p, np.clip(rgb, 0, 255).astype(np.uint8), georef)
     inputs.append(p)
 
+from app.tiling import process_raster_to_tiles  # noqa: E402
 from app.wow_sr import process_wow_sr  # noqa: E402
 
 cases = [(p, ec, m) for p in inputs for ec in (True, False) for m in ("realesrgan_x4", "realesrgan_anime")]
@@ -57,6 +59,16 @@ def worker(t):
         try:
             res = process_wow_sr(p, out, enhance_crops=ec, model=m)
             d = hashlib.sha256(Path(res["outputs"]["sr_png"]).read_bytes()).hexdigest()
+            if k % 3 == 0:                          # the tiling stage of a job (main.py:347-359), on the shared pyramid engine
+                td = out / "tiles"
+                shutil.rmtree(td, ignore_errors=True)             # the directory is reused by other cases with other tile sets
+                process_raster_to_tiles(Path(res["outputs"]["sr_tif"]), td, 10, 15)
+                d += hashlib.sha256(b"".join(q.read_bytes() for q in sorted(td.glob("*/*/*.png")))).hexdigest()
+                tiles_key = ("tiles", ci)
+                with lock:
+                    if first.setdefault(tiles_key, d) != d:
+                        errors.append(f"thread {t} case {ci}: tiles differ from the first pyramid of this case")
+                d = d[:64]
         except Exception as e:  # noqa: BLE001
             errors.append(f"thread {t} case {ci}: {type(e).__name__}: {e}")
             return
