@@ -213,9 +213,12 @@ int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, i
  * write_png: the PNG files (8-bit RGBA, what s2sr_png_encode writes up to the tokenisation: runs do not cross rows) of the level the
  * previous base / overview call produced, encoded on the device: token statistics and bit emission are kernels, the Huffman codes
  * come from the host between them, only compressed bytes cross PCIe.  paths: nx * ny entries, row-major like the tile array, NULL =
- * skip; skip_transparent: no file for a tile whose alpha is 0 everywhere; written (optional): 1 per file written.  Missing parent
- * directories are created. */
-int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t skip_transparent, int32_t* written);
+ * skip; flags: S2SR_PNG_SKIP_TRANSPARENT = no file for a tile whose alpha is 0 everywhere, S2SR_PNG_HOST_ENCODER = every tile
+ * through the host encoder (the route a tile takes by itself when stored blocks would be smaller; a diagnostic); written
+ * (optional): 1 per file written.  Missing parent directories are created. */
+#define S2SR_PNG_SKIP_TRANSPARENT 1
+#define S2SR_PNG_HOST_ENCODER     2
+int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written);
 
 /* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;
  * on = N >= 1: every N-th launch of each family is bracketed by a hipEvent pair (N > 1 keeps

@@ -1045,10 +1045,12 @@ static hipError_t launch_t(const ConvParams& p, hipStream_t st) {
 
 // S2SR_W4=1: the RDB convs as 4-wave workgroups, one wave per SIMD with the 512-register budget
 // (8 / 4 rows per wave), instead of 8 waves x 4 / 2 rows
+#if S2SR_EXPERIMENTAL
 static bool use_w4() {
     static const bool v = [] { const char* e = getenv("S2SR_W4"); return e && atoi(e) != 0; }();
     return v;
 }
+#endif
 
 template <int CT, int EPI, bool UP>
 static hipError_t launch_w(const ConvParams& p, hipStream_t st) {
@@ -1250,7 +1252,11 @@ static void pack_f8hp_taps(const float* w, int cin, int cout, int taps, void* ds
                         *d16++ = o;
                     }
     uint8_t* d = (uint8_t*)d16;
+#if S2SR_EXPERIMENTAL
     static const bool diag_no_wlo = [] { const char* e = getenv("S2SR_DIAG_NO_WLO"); return e && atoi(e) != 0; }();   // numerics diagnostic
+#else
+    const bool diag_no_wlo = false;
+#endif
     for (int part = 0; part < (fold ? 1 : 2); ++part)                   // 0: w_hi (meets x_lo), 1: w_lo * 2^11 (meets x_hi)
         for (int pl = 0; pl < 2; ++pl)
             for (int t = 0; t < taps; ++t)

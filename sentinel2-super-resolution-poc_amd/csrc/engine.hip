@@ -1799,7 +1799,7 @@ int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, in
 // The PNG files of the tile level the previous base / overview call left on the device: token statistics on the device, Huffman
 // codes on the host, bit emission on the device, chunk framing + CRC + file writes on host threads (pngdev.hip).  Only the
 // compressed streams cross PCIe.
-int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t skip_transparent, int32_t* written) {
+int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written) {
     if (!h || !paths || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -1828,7 +1828,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
     T[1] = now();
     PngTilePlan plan;
     const size_t out_words = png_plan_tiles(n, stats.data(), stats.data() + (size_t)n * 512, stats.data() + (size_t)n * 1024, paths,
-                                            skip_transparent != 0, &plan);
+                                            (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &plan);
     T[2] = now();
     const size_t tb_b = plan.tb.size() * 4, hdr_b = plan.hdr.size() * 4, meta_b = plan.meta.size();
     if ((rc = ensure_scratch(h, 3, tb_b + hdr_b + meta_b))) return rc;
@@ -2349,7 +2349,11 @@ int s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
+#if S2SR_EXPERIMENTAL
     const bool timed_trace = trace && trace_wgs > 0 && getenv("S2SR_TRACE_TIMED");   // time the TRACE build (ablations)
+#else
+    const bool timed_trace = false;
+#endif
     if (timed_trace) {
         HIPCHK(h, dev_malloc(&d_tr, (size_t)256 * 24 * 8));
         p.trace = d_tr;

@@ -193,7 +193,7 @@ hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* 
 // size of its deflate bytes.  mode[t]: 0 = nothing to write (no path, or fully transparent), 1 = device stream, 2 = host encoder
 // (stored blocks would be smaller than this tile's Huffman block).  Returns the number of 32-bit words the output buffer needs.
 size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
-                      bool skip_transparent, PngTilePlan* plan) {
+                      bool skip_transparent, bool force_host, PngTilePlan* plan) {
     plan->mode.assign(n, 0);
     plan->adler.assign(n, 0);
     plan->deflate_bytes.assign(n, 0);
@@ -203,8 +203,6 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     plan->hdr.assign((size_t)n * 160, 0);
     plan->meta.assign((size_t)n * sizeof(TileMeta), 0);
     std::vector<uint32_t> words(n, 0);
-    const char* fh = getenv("S2SR_PNG_FORCE_HOST");      // diagnostic: every tile through the host encoder (the route of incompressible tiles)
-    const bool force_host = fh && atoi(fh) != 0;
     parallel_for(n, [&](int t) {
         TileMeta* m = (TileMeta*)plan->meta.data() + t;
         m->skip = 1;

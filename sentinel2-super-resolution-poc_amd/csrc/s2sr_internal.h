@@ -237,7 +237,7 @@ hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d
 hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* d_meta, const uint32_t* d_tb, const uint32_t* d_hdr,
                                 uint32_t* d_out, hipStream_t st);
 size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
-                      bool skip_transparent, PngTilePlan* plan);
+                      bool skip_transparent, bool force_host, PngTilePlan* plan);
 bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t deflate_bytes, uint32_t eob, uint64_t eob_at, uint32_t adler,
                          std::vector<uint8_t>& buf);
 void png_parallel_for(int n, const std::function<void(int)>& body);

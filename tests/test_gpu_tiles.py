@@ -75,7 +75,7 @@ def test_base_and_overview_bit_exact(eng):
         eng.tiles_base_u8(rgba, *bad)
 
 
-def test_level_pngs_encoded_on_the_device(eng, tmp_path, monkeypatch):
+def test_level_pngs_encoded_on_the_device(eng, tmp_path):
     """s2sr_tiles_write_png: the level stays on the device, its PNG files must decode to exactly the tiles a fetch returns --
     smooth tiles (Huffman blocks with runs), noise tiles (handed to the host encoder: stored blocks), half-covered tiles,
     fully transparent ones (no file), skipped paths."""
@@ -121,7 +121,7 @@ def test_level_pngs_encoded_on_the_device(eng, tmp_path, monkeypatch):
     assert not want[..., 3].all() or True
     # A level made of the raster's own pixels (footprint tables of one pixel each): noise, a flat and a transparent tile.  Level
     # alpha is 0 or 255, so even noise keeps a compressible channel and stays on the device route; the host-encoder route (taken
-    # when stored blocks would be smaller, or a block header outgrows its slot) is forced once through its diagnostic switch.
+    # when stored blocks would be smaller, or a block header outgrows its slot) is forced once through its flag.
     noise = rng.integers(0, 256, (512, 512, 4), dtype=np.uint8)
     noise[..., 3] = 255
     noise[256:, :256, :3] = 77
@@ -129,15 +129,13 @@ def test_level_pngs_encoded_on_the_device(eng, tmp_path, monkeypatch):
     ident = np.arange(512, dtype=np.int32)
     got = eng.tiles_base_u8(noise, ident, ident, ident, ident)
     assert np.array_equal(got[1, 0], noise[256:, :256]) and np.array_equal(got[0, 1], noise[:256, 256:])
-    for force_host in ("0", "1"):
-        monkeypatch.setenv("S2SR_PNG_FORCE_HOST", force_host)
+    for force_host in (False, True):
         eng.tiles_base_u8(noise, ident, ident, ident, ident, fetch=False)
-        npaths = [tmp_path / f"noise{force_host}" / f"{j}_{i}.png" for j in range(2) for i in range(2)]
-        assert eng.tiles_write_png(2, 2, npaths).tolist() == [[1, 1], [1, 0]]
+        npaths = [tmp_path / f"noise{int(force_host)}" / f"{j}_{i}.png" for j in range(2) for i in range(2)]
+        assert eng.tiles_write_png(2, 2, npaths, host_encoder=force_host).tolist() == [[1, 1], [1, 0]]
         for q, (j, i) in zip(npaths[:3], ((0, 0), (0, 1), (1, 0))):
             assert np.array_equal(np.asarray(Image.open(q)), got[j, i]), (force_host, j, i)
         assert npaths[2].stat().st_size < 2_000 and not npaths[3].exists()
-    monkeypatch.delenv("S2SR_PNG_FORCE_HOST")
     eng.postprocess_u8(np.zeros((64, 64, 3), np.uint8), native.pp_wow())           # any other call takes the scratch
     with pytest.raises(native.S2srError, match="did not leave a tile level"):
         eng.tiles_write_png(1, 1, [tmp_path / "x.png"])
