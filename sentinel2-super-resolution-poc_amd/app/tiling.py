@@ -62,16 +62,24 @@ def encode_png_rgba(tile: np.ndarray, level: int = 1, strategy: int = zlib.Z_RLE
         return native.png_encode(tile)
     return _png_from_filtered(filter_sub_rgba(tile), level, strategy)
 
-_ENGINE: Optional[native.Engine] = None
-_PYRAMID_LOCK = threading.Lock()
+_ENGINES: dict = {}                 # device index -> (engine, lock of its pyramid chain)
+_ENGINES_LOCK = threading.Lock()
+
+
+def _engine_and_lock():
+    """The pyramid engine of the GPU this job was admitted to (app.sr_routes.GpuAdmission sets the thread's device; default:
+    LOCAL_RANK, as everywhere in app.*) and the lock that keeps one pyramid chain at a time on it.  A weightless handle is enough
+    for the pyramid kernels (raises without a gfx950 GPU)."""
+    from app.cnn_super_resolution import current_device_index
+    dev = current_device_index()
+    with _ENGINES_LOCK:
+        if dev not in _ENGINES:
+            _ENGINES[dev] = (native.Engine(num_block=1, device=dev), threading.Lock())
+        return _ENGINES[dev]
 
 
 def _engine() -> native.Engine:
-    """A weightless handle is enough for the pyramid kernels (raises without a gfx950 GPU)."""
-    global _ENGINE
-    if _ENGINE is None:
-        _ENGINE = native.Engine(num_block=1)
-    return _ENGINE
+    return _engine_and_lock()[0]
 
 
 @dataclass
@@ -129,8 +137,9 @@ def reproject_to_web_mercator(input_path: Path, output_path: Path, resample_meth
     arr, _tags, place, crs = _read(input_path)
     rgb = rio._to_u8(arr[..., :3] if arr.shape[2] >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
     plan = tiles.plan_warp(rgb.shape[1], rgb.shape[0], place, crs)
-    with _PYRAMID_LOCK:          # the shared engine's scratch holds a pyramid chain's previous level (see _cut_pyramid)
-        out = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    eng, lock = _engine_and_lock()
+    with lock:                   # the engine's scratch holds a pyramid chain's previous level (see _cut_pyramid)
+        out = eng.warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
     output_path.parent.mkdir(parents=True, exist_ok=True)
     rio.write_geotiff_rgb(output_path, np.ascontiguousarray(out[..., :3]), _mercator_tags(plan.placement))
     logger.info("Reprojection complete: %s", output_path)
@@ -149,12 +158,12 @@ def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_z
     import time
     h, w = rgba.shape[:2]
     output_dir.mkdir(parents=True, exist_ok=True)
-    eng = _engine()
+    eng, lock = _engine_and_lock()
     levels = tiles.plan_levels(place.bounds(w, h), min_zoom, max_zoom)
     prev_lv = None
     t_dev = t_png = 0.0
-    # the levels of one pyramid chain through the engine's device copy of the previous level: one pyramid at a time on the shared engine
-    with _PYRAMID_LOCK:
+    # the levels of one pyramid chain through the engine's device copy of the previous level: one pyramid at a time per engine
+    with lock:
         for lv in levels:
             t0 = time.perf_counter()
             if prev_lv is None:
@@ -222,8 +231,9 @@ def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 1
         # but the pyramid is cut from the array in hand, with the coverage mask of the warp as alpha
         plan = tiles.plan_warp(w, h, place, crs)
         t2 = time.perf_counter()
-        with _PYRAMID_LOCK:
-            rgba = _engine().warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+        eng, lock = _engine_and_lock()
+        with lock:
+            rgba = eng.warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
         t3 = time.perf_counter()
         place = plan.placement
         LAST_STATS.update(warp_plan=t2 - t1, warp_call=t3 - t2)
