@@ -218,6 +218,7 @@ int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, i
  * (optional): 1 per file written.  Missing parent directories are created. */
 #define S2SR_PNG_SKIP_TRANSPARENT 1
 #define S2SR_PNG_HOST_ENCODER     2
+#define S2SR_PNG_ROW_THREADS      4   /* the first form of the two kernels (one thread walks one row): same bytes, kept as the check */
 int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written);
 
 /* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;

@@ -1820,7 +1820,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
     uint32_t* d_flag = d_adl + (size_t)n * 512;
     {
         Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0);      // algorithmic: every tile byte once
-        HIPCHK(h, launch_png_tile_stats(d_tiles, n, d_hist, d_adl, d_flag, st));
+        HIPCHK(h, launch_png_tile_stats(d_tiles, n, d_hist, d_adl, d_flag, (flags & S2SR_PNG_ROW_THREADS) != 0, st));
     }
     std::vector<uint32_t> stats((hist_b + adl_b + flag_b) / 4);
     HIPCHK(h, hipMemcpyAsync(stats.data(), d_hist, hist_b + adl_b + flag_b, hipMemcpyDeviceToHost, st));
@@ -1841,7 +1841,8 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
     HIPCHK(h, hipMemsetAsync(d_out, 0, (out_words + 1) * 4, st));
     {
         Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0 + (double)out_words * 4.0);
-        HIPCHK(h, launch_png_tile_emit(d_tiles, n, d_tb + tb_b + hdr_b, (const uint32_t*)d_tb, (const uint32_t*)(d_tb + tb_b), d_out, st));
+        HIPCHK(h, launch_png_tile_emit(d_tiles, n, d_tb + tb_b + hdr_b, (const uint32_t*)d_tb, (const uint32_t*)(d_tb + tb_b), d_out,
+                                       (flags & S2SR_PNG_ROW_THREADS) != 0, st));
     }
     if (timing) { HIPCHK(h, hipStreamSynchronize(st)); }
     T[3] = now();

@@ -102,6 +102,126 @@ __global__ void __launch_bounds__(256) png_tile_stats_kernel(const uint8_t* __re
     if (threadIdx.x == 0) flags[t] = any_alpha;
 }
 
+// ---- one wave per row --------------------------------------------------------------------------
+// The same token stream as walk_row, computed without a serial walk: lane l owns stream bytes 16 l .. 16 l + 15 of the row (one
+// coalesced 1-KB load per wave).  e[p] = "byte p equals byte p - 1" as a 16-bit mask per lane; a maximal stretch of e = 1 is a
+// run of R bytes behind a literal, cut into chunks of 258 from its start: a chunk of c >= 3 bytes is ONE match token at its
+// first byte, a last chunk of 1 or 2 bytes stays literals.  What a lane needs from its neighbours -- how many e = 1 bytes lie
+// directly in front of its first byte (P) and directly behind its last one (S) -- comes from one ballot of the "all 16 equal"
+// lanes and two shuffles.  No branch depends on the data.
+struct RowTokens {
+    uint32_t tok[16];       // token at each of the lane's 16 positions (valid where bit i of `valid` is set)
+    uint32_t valid;
+    uint32_t f[4];          // the 16 filtered bytes
+};
+
+__device__ __forceinline__ uint32_t sub_bytes(uint32_t a, uint32_t b) {   // four byte-wise a - b
+    return ((a | 0x80808080u) - (b & 0x7F7F7F7Fu)) ^ ((a ^ ~b) & 0x80808080u);
+}
+__device__ __forceinline__ uint32_t zero_byte_bits(uint32_t x) {         // bit k set where byte k of x is zero
+    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);     // 0x80 in every zero byte
+    return ((((z >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+
+__device__ __forceinline__ void row_tokens(const uint4 v, int lane, RowTokens& rt, uint32_t& alpha_bits) {   // v: the lane's 16 bytes of the row
+    alpha_bits = (v.x | v.y | v.z | v.w) >> 24;
+    uint32_t left = __shfl_up(v.w, 1);
+    if (lane == 0) left = 0;
+    rt.f[0] = sub_bytes(v.x, left);
+    rt.f[1] = sub_bytes(v.y, v.x);
+    rt.f[2] = sub_bytes(v.z, v.y);
+    rt.f[3] = sub_bytes(v.w, v.z);
+    uint32_t prevb = __shfl_up(rt.f[3] >> 24, 1);
+    if (lane == 0) prevb = 1;                                    // the filter-type byte in front of the row
+    const uint32_t s0 = (rt.f[0] << 8) | prevb, s1 = (rt.f[1] << 8) | (rt.f[0] >> 24), s2 = (rt.f[2] << 8) | (rt.f[1] >> 24),
+                   s3 = (rt.f[3] << 8) | (rt.f[2] >> 24);
+    const uint32_t E = zero_byte_bits(rt.f[0] ^ s0) | (zero_byte_bits(rt.f[1] ^ s1) << 4) | (zero_byte_bits(rt.f[2] ^ s2) << 8) |
+                       (zero_byte_bits(rt.f[3] ^ s3) << 12);
+    const bool full = E == 0xFFFFu;
+    const int lead = full ? 16 : __builtin_ctz(~E);                         // e = 1 bytes from the lane's first byte on
+    const int trail = full ? 16 : __builtin_clz((~E & 0xFFFFu) << 16);      // ... up to its last byte
+    const unsigned long long F = __ballot(full);
+    const unsigned long long below = ~F & ((1ull << lane) - 1ull);
+    const int j = below ? 63 - __builtin_clzll(below) : 0;
+    const int trail_j = __shfl(trail, j);
+    const int P = below ? 16 * (lane - 1 - j) + trail_j : 16 * lane;
+    const unsigned long long above = lane == 63 ? 0ull : (~F & ~((2ull << lane) - 1ull));
+    const int k = above ? __builtin_ctzll(above) : 63;
+    const int lead_k = __shfl(lead, k);
+    const int S = above ? 16 * (k - lane - 1) + lead_k : 16 * (63 - lane);
+    rt.valid = 0;
+    int q = 0, R = 0;                                            // position inside the current run, its length
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t fb = (rt.f[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const bool e = (E >> i) & 1u;
+        const bool starts = e && (i == 0 || !((E >> (i - 1)) & 1u));
+        if (i == 0) {                                            // a run that comes in from the left
+            q = P;
+            R = P + lead + (lead == 16 ? S : 0);
+        } else if (starts) {
+            const uint32_t rest = ~(E >> i) & (0xFFFFu >> i);    // first e = 0 behind i, inside the lane
+            const int len = rest ? __builtin_ctz(rest) : 16 - i;
+            q = 0;
+            R = len + (len == 16 - i ? S : 0);
+        } else {
+            ++q;
+        }
+        const int qm = q < 258 ? q : q < 516 ? q - 258 : q < 774 ? q - 516 : q - 774;     // q mod 258 (q < 1032)
+        const int c = min(258, R - (q - qm));                    // length of the chunk this byte is in
+        const bool is_match = e && c >= 3 && qm == 0;
+        const bool is_lit = !e || c < 3;
+        rt.tok[i] = is_match ? 256u + (uint32_t)(c - 3) : fb;
+        rt.valid |= (uint32_t)(is_match || is_lit) << i;
+    }
+}
+
+__global__ void __launch_bounds__(256) png_tile_stats_wave_kernel(const uint8_t* __restrict__ tiles, int ntiles, uint32_t* __restrict__ hist,
+                                                                  uint32_t* __restrict__ adler, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t h[4][512];
+    __shared__ uint32_t any_alpha;
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    for (int i = threadIdx.x; i < 4 * 512; i += 256) (&h[0][0])[i] = 0;
+    if (threadIdx.x == 0) any_alpha = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* hw = h[wave];
+    uint32_t alpha = 0;
+    const uint4* rows = (const uint4*)(tiles + (size_t)t * kRows * kRow) + lane;      // row r of this lane: rows[r * 64]
+    uint4 vn = rows[(size_t)wave * 64];
+    for (int r = wave; r < kRows; r += 4) {
+        const uint4 v = vn;
+        if (r + 4 < kRows) vn = rows[(size_t)(r + 4) * 64];     // the next row is on its way while this one is worked on
+        RowTokens rt;
+        uint32_t ab;
+        row_tokens(v, lane, rt, ab);
+        alpha |= ab;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((rt.valid >> i) & 1u) atomicAdd(&hw[rt.tok[i]], 1u);
+        // Adler partial sums of the row's 1025 stream bytes (filter byte first): A = sum x_i, B = sum (1025 - i) x_i
+        uint32_t A = 0, B = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t fb = (rt.f[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            A += fb;
+            B += fb * (uint32_t)(kRow - (16 * lane + i));         // stream index 1 + 16 lane + i
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); B += __shfl_xor(B, o); }
+        if (lane == 0) {
+            adler[((size_t)t * kRows + r) * 2] = A + 1u;
+            adler[((size_t)t * kRows + r) * 2 + 1] = B + (uint32_t)(kRow + 1);
+        }
+    }
+    if (lane == 0) atomicAdd(&hw[1], (uint32_t)(kRows / 4));       // 64 rows per wave, one filter-byte literal each
+    if (alpha) atomicOr(&any_alpha, 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) hist[(size_t)t * 512 + i] = h[0][i] + h[1][i] + h[2][i] + h[3][i];
+    if (threadIdx.x == 0) flags[t] = any_alpha;
+}
+
 struct TileMeta {
     uint64_t out_word;      // first 32-bit word of the tile's region in the output buffer
     uint32_t header_bits;   // block header bits in front of the rows' bits
@@ -148,6 +268,101 @@ __global__ void __launch_bounds__(256) png_tile_emit_kernel(const uint8_t* __res
     if (n > 0) atomicOr(&o[w], (uint32_t)acc);
 }
 
+__global__ void __launch_bounds__(256) png_tile_emit_wave_kernel(const uint8_t* __restrict__ tiles, int ntiles, const TileMeta* __restrict__ meta,
+                                                                 const uint32_t* __restrict__ tbs, const uint32_t* __restrict__ hdrs,
+                                                                 uint32_t* __restrict__ out) {
+    __shared__ uint32_t tb[512];
+    __shared__ uint32_t row_bits[kRows];
+    __shared__ uint32_t rowbuf[4][512];
+    const int t = blockIdx.x;
+    if (t >= ntiles) return;
+    const TileMeta m = meta[t];
+    if (m.skip) return;
+    for (int i = threadIdx.x; i < 512; i += 256) tb[i] = tbs[(size_t)t * 512 + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lit1_bits = tb[1] >> 24;                      // the filter byte's literal in front of every row
+    const uint4* rows = (const uint4*)(tiles + (size_t)t * kRows * kRow) + lane;      // row r of this lane: rows[r * 64]
+    uint4 vn = rows[(size_t)wave * 64];
+    for (int r = wave; r < kRows; r += 4) {
+        const uint4 v = vn;
+        if (r + 4 < kRows) vn = rows[(size_t)(r + 4) * 64];
+        RowTokens rt;
+        uint32_t ab;
+        row_tokens(v, lane, rt, ab);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bits += ((rt.valid >> i) & 1u) ? (tb[rt.tok[i]] >> 24) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bits += __shfl_xor(bits, o);
+        if (lane == 0) row_bits[r] = bits + lit1_bits;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                          // exclusive scan of 256 values
+        uint32_t acc = m.header_bits;
+        for (int r = 0; r < kRows; ++r) { const uint32_t v = row_bits[r]; row_bits[r] = acc; acc += v; }
+    }
+    __syncthreads();
+    uint32_t* o = out + m.out_word;
+    for (uint32_t w = threadIdx.x; w * 32 < m.header_bits; w += 256) atomicOr(&o[w], hdrs[(size_t)t * 160 + w]);
+    vn = rows[(size_t)wave * 64];
+    for (int r = wave; r < kRows; r += 4) {
+        const uint4 v = vn;
+        if (r + 4 < kRows) vn = rows[(size_t)(r + 4) * 64];
+        RowTokens rt;
+        uint32_t ab;
+        row_tokens(v, lane, rt, ab);
+        // the lane's tokens as one bit string (at most 16 x 21 bits, + the filter byte's literal in lane 0), assembled in the
+        // wave's LDS row buffer: a row is at most 1025 x 15 bits (all literals at the longest code) + 31 bits of offset = 482 words
+        uint32_t bits = lane == 0 ? lit1_bits : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bits += ((rt.valid >> i) & 1u) ? (tb[rt.tok[i]] >> 24) : 0u;
+        uint32_t incl = bits;                                    // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t row_at = row_bits[r];                     // bit offset of the row in the tile's stream
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t nwords = ((row_at & 31u) + total + 31u) >> 5;
+        uint32_t* rb = rowbuf[wave];
+        for (uint32_t w = lane; w < nwords; w += 64) rb[w] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t at = (row_at & 31u) + (incl - bits);
+        uint32_t w = at >> 5;
+        uint64_t acc = 0;
+        int n = (int)(at & 31u);
+        if (lane == 0) {
+            acc |= (uint64_t)(tb[1] & 0xFFFFFFu) << n;
+            n += (int)lit1_bits;
+            if (n >= 32) { atomicOr(&rb[w++], (uint32_t)acc); acc >>= 32; n -= 32; }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((rt.valid >> i) & 1u) {
+                const uint32_t e = tb[rt.tok[i]];
+                acc |= (uint64_t)(e & 0xFFFFFFu) << n;
+                n += (int)(e >> 24);
+                if (n >= 32) { atomicOr(&rb[w++], (uint32_t)acc); acc >>= 32; n -= 32; }
+            }
+        }
+        if (n > 0 && acc) atomicOr(&rb[w], (uint32_t)acc);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // out: the first and the last word are shared with the neighbouring rows, the ones between belong to this row alone
+        uint32_t* og = o + (row_at >> 5);
+        for (uint32_t k = lane; k < nwords; k += 64) {
+            const uint32_t val = rb[k];
+            if (k == 0 || k + 1 == nwords) { if (val) atomicOr(&og[k], val); }
+            else og[k] = val;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int host_threads() {
     int n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 4;
@@ -175,16 +390,22 @@ template <class F> void parallel_for(int n, F&& body) {      // body(i) for i in
 
 }  // namespace
 
-hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, hipStream_t st) {
+hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, bool row_threads,
+                                 hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(png_tile_stats_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, d_hist, d_adler, d_flags);
+    if (row_threads) hipLaunchKernelGGL(png_tile_stats_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, d_hist, d_adler, d_flags);
+    else hipLaunchKernelGGL(png_tile_stats_wave_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, d_hist, d_adler, d_flags);
     return hipGetLastError();
 }
 
 hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* d_meta, const uint32_t* d_tb, const uint32_t* d_hdr,
-                                uint32_t* d_out, hipStream_t st) {
+                                uint32_t* d_out, bool row_threads, hipStream_t st) {
     if (ntiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(png_tile_emit_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, (const TileMeta*)d_meta, d_tb, d_hdr, d_out);
+    if (row_threads)
+        hipLaunchKernelGGL(png_tile_emit_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, (const TileMeta*)d_meta, d_tb, d_hdr, d_out);
+    else
+        hipLaunchKernelGGL(png_tile_emit_wave_kernel, dim3(ntiles), dim3(256), 0, st, d_tiles, ntiles, (const TileMeta*)d_meta, d_tb, d_hdr,
+                           d_out);
     return hipGetLastError();
 }
 

@@ -604,14 +604,15 @@ class Engine:
                     "s2sr_tiles_overview_u8")
         return out
 
-    def tiles_write_png(self, nx: int, ny: int, paths, skip_transparent: bool = True, host_encoder: bool = False) -> np.ndarray:
+    def tiles_write_png(self, nx: int, ny: int, paths, skip_transparent: bool = True, host_encoder: bool = False,
+                        row_threads: bool = False) -> np.ndarray:
         """The PNG files of the level the previous tiles call left on the device, encoded there (s2sr_tiles_write_png): `paths` has
         ny * nx entries in the tile array's order (None = skip).  Returns the 0/1 array [ny, nx] of files written."""
         if len(paths) != nx * ny:
             raise ValueError(f"{nx * ny} tiles, {len(paths)} paths")
         cp = (C.c_char_p * (nx * ny))(*[None if p is None else os.fsencode(p) for p in paths])
         written = np.zeros(nx * ny, np.int32)
-        self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent) | (2 if host_encoder else 0),
+        self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent) | (2 if host_encoder else 0) | (4 if row_threads else 0),
                                                    written.ctypes.data_as(C.POINTER(C.c_int32))),
                     "s2sr_tiles_write_png")
         return written.reshape(ny, nx)

@@ -141,6 +141,53 @@ def test_level_pngs_encoded_on_the_device(eng, tmp_path):
         eng.tiles_write_png(1, 1, [tmp_path / "x.png"])
 
 
+def test_tile_png_kernel_forms_write_the_same_bytes(eng, tmp_path):
+    """The two kernels of s2sr_tiles_write_png exist in two forms -- one thread walks one row (the first, kept as the check), one
+    wave per row with the run structure from a ballot and two shuffles (the default) -- and must produce the same token stream:
+    the files are compared byte for byte.  Rows are built from their Sub-filtered bytes: zero stretches of every length around
+    the interesting ones (1, 2, 3 bytes: literals or a match; 258 + 1 / 2 / 3: the chunk rule; beyond 516 and 774; across the
+    16-byte lane boundaries), noise, flat rows, runs that start at the filter byte."""
+    from PIL import Image
+    rng = np.random.default_rng(17)
+    H = W = 512
+    lens = [1, 2, 3, 4, 5, 14, 15, 16, 17, 18, 31, 32, 33, 63, 64, 65, 255, 256, 257, 258, 259, 260, 261, 262, 300, 514, 515, 516, 517, 518, 519,
+            520, 773, 774, 775, 776, 777, 1000, 1020]
+    img = np.zeros((H, W, 4), np.uint8)
+    for y in range(H):
+        g = np.zeros((W, 3), np.int64)                       # per-pixel colour deltas: the filtered bytes (alpha's delta is 0)
+        kind = y % 5
+        if kind == 0:                                        # zero stretches of chosen lengths between single non-zero bytes
+            flat = np.zeros(W * 3, np.int64)
+            pos = int(rng.integers(0, 8))
+            while pos < flat.size:
+                flat[pos] = int(rng.integers(1, 256))
+                pos += 1 + int(lens[int(rng.integers(len(lens)))]) * 3 // 4
+            g = flat.reshape(W, 3)
+        elif kind == 1:
+            g = rng.integers(0, 256, (W, 3))                 # noise
+        elif kind == 2:
+            g[rng.random(W) < 0.03] = rng.integers(1, 256, 3)     # sparse steps: long flat stretches
+        elif kind == 3:
+            g[:] = 1 if y % 2 else 0                         # all-ones deltas (a run that starts at the filter byte 1) / all zero
+            g[0] = (1, 1, 1)
+        else:
+            g[::int(rng.integers(2, 70))] = rng.integers(0, 3, 3)
+        img[y, :, :3] = np.cumsum(g, axis=0) % 256
+    img[..., 3] = 255
+    ident = np.arange(512, dtype=np.int32)
+    got = eng.tiles_base_u8(img, ident, ident, ident, ident)
+    assert np.array_equal(got[0, 0], img[:256, :256])
+    files = {}
+    for form in (False, True):
+        eng.tiles_base_u8(img, ident, ident, ident, ident, fetch=False)
+        paths = [tmp_path / f"form{int(form)}" / f"{j}_{i}.png" for j in range(2) for i in range(2)]
+        assert eng.tiles_write_png(2, 2, paths, row_threads=form).all()
+        files[form] = [q.read_bytes() for q in paths]
+        for q, (j, i) in zip(paths, ((0, 0), (0, 1), (1, 0), (1, 1))):
+            assert np.array_equal(np.asarray(Image.open(q)), got[j, i]), (form, j, i)
+    assert files[False] == files[True]
+
+
 def test_process_raster_to_tiles_end_to_end(tmp_path):
     import app.tiling as tiling
     rgb = _scene(240, 320, seed=5)
