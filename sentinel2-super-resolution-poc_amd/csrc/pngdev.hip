@@ -2,16 +2,17 @@
 // deflate them on 16 host CPUs was the whole cost of the stage: 0.2 s of copies + 0.3 s of encoders).  The level stays where the
 // pyramid kernels left it; what crosses PCIe is the compressed stream (~70 KB per tile instead of 256 KB).
 //
-//   stats kernel   one workgroup per tile, one thread per row: the row's byte stream (filter byte 1, 1024 Sub-filtered bytes) is
-//                  walked once -- distance-1 runs inside the row become matches, the rest literals (the host encoder's token
-//                  alphabet, png_internal.h) -- into a per-tile token histogram (LDS, one table per wave), the row's Adler-32
-//                  partial sums and the tile's "any alpha" flag.
+//   stats kernel   one workgroup per tile, one WAVE per row (lane l owns bytes 16 l .. 16 l + 15 of the row's stream: filter byte 1
+//                  + 1024 Sub-filtered bytes): distance-1 runs inside the row become matches, the rest literals (the host
+//                  encoder's token alphabet, png_internal.h) -- into a per-tile token histogram (LDS, one table per wave), the
+//                  row's Adler-32 partial sums and the tile's "any alpha" flag.
 //   host           per tile: Huffman code + block header from the histogram (build_block_code, the host encoder's own), the exact
 //                  compressed size (so the output buffer is laid out exactly), Adler-32 from the row sums.  Tiles that stored
 //                  blocks would serve better (noise) go to the host encoder.
-//   emit kernel    same walk twice: bits per row -> exclusive scan -> every row ORs its bits into the stream at its offset.
+//   emit kernel    the rows again, twice: bits per row -> exclusive scan -> every row assembled in LDS and written at its offset.
 //   host           chunk framing, CRC-32, file write, on threads.
-// Integer / byte work, HBM- (in fact L2-) bound: a tile is read three times as 16-byte loads, each row by one lane.
+// Integer / byte work.  The first form of the two kernels (one THREAD walks one row byte by byte: walk_row, *_kernel without
+// "wave") is kept behind S2SR_PNG_ROW_THREADS as the check: both forms must write the same bytes (tests/test_gpu_tiles.py).
 #include <stdlib.h>
 #include <string.h>
 
