@@ -258,3 +258,20 @@ def test_http_wow_job_tiles_by_default(monkeypatch, tmp_path):
         assert pngs and np.asarray(Image.open(pngs[0])).shape == (256, 256, 4)
     lon, lat = geo.CRS(32633).to_lonlat(600160.0, 5099880.0)       # centre of the 320 m x 240 m scene
     assert meta["bounds"][0] < float(lon) < meta["bounds"][2] and meta["bounds"][1] < float(lat) < meta["bounds"][3]
+
+
+def test_gpu_pyramid_against_gdal_golden(golden_dir, tmp_path):
+    """With tests/golden/g10_gdal_tiles.npz present (tools/make_gdal_golden.py, run where GDAL's tools are installed): the pyramid
+    this build writes for the same GeoTIFF against gdalwarp + gdal2tiles.py's.  Skips without the file (this container has no GDAL)."""
+    import app.tiling as tiling
+    f = golden_dir / "g10_gdal_tiles.npz"
+    if not f.exists():
+        pytest.skip("tests/golden/g10_gdal_tiles.npz absent: run tools/make_gdal_golden.py where gdalwarp / gdal2tiles.py exist")
+    g = np.load(f)
+    georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                         rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+    rio.write_geotiff_rgb(tmp_path / "aoi.tif", g["rgb"], georef)
+    tiling.process_raster_to_tiles(tmp_path / "aoi.tif", tmp_path / "tiles", int(g["min_zoom"]), int(g["max_zoom"]))
+    from gdal_compare import compare_with_gdal
+    ours = {f"tile_{q.parts[-3]}_{q.parts[-2]}_{q.stem}": np.asarray(Image.open(q).convert("RGBA")) for q in (tmp_path / "tiles").glob("*/*/*.png")}
+    compare_with_gdal(g, ours)

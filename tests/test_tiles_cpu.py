@@ -159,3 +159,34 @@ def test_tileset_metadata_contract(tmp_path):
     assert m == {"bounds": [16.29, 46.03, 16.31, 46.05], "minzoom": 10, "maxzoom": 18,
                  "tileTemplate": "/tiles/{z}/{x}/{y}.png", "attribution": "Sentinel-2 SR via UP42", "format": "png",
                  "tileSize": 256}
+
+
+def test_oracle_against_gdal_golden(golden_dir):
+    """With tests/golden/g10_gdal_tiles.npz present (tools/make_gdal_golden.py, run where gdalwarp / gdal2tiles.py exist): the
+    oracle's pyramid (oracle/tiles_ref.py: bilinear warp, footprint-average base tiles, 2x2-average overviews) for the same
+    raster against GDAL's.  Skips without the file (this container has no GDAL; DESIGN.md: "unpinned")."""
+    import pytest
+    from gdal_compare import compare_with_gdal
+    f = golden_dir / "g10_gdal_tiles.npz"
+    if not f.exists():
+        pytest.skip("tests/golden/g10_gdal_tiles.npz absent: run tools/make_gdal_golden.py where gdalwarp / gdal2tiles.py exist")
+    g = np.load(f)
+    rgb = g["rgb"]
+    h, w = rgb.shape[:2]
+    plan = tiles.plan_warp(w, h, geo.Placement(600000.0, 5100000.0, 2.5, 2.5), geo.CRS(32633))
+    rgba = ref.warp_bilinear(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
+    place = plan.placement
+    levels = tiles.plan_levels(place.bounds(plan.out_w, plan.out_h), int(g["min_zoom"]), int(g["max_zoom"]))
+    ours, prev, prev_lv = {}, None, None
+    for lv in levels:
+        if prev is None:
+            cur = np.stack([np.stack([ref.base_tile(rgba, place.x0, place.y0, place.dx, place.dy, lv.tminx + i, lv.tmaxy - j, lv.zoom)
+                                      for i in range(lv.nx)]) for j in range(lv.ny)])
+        else:
+            cur = ref.overview(prev, *tiles.overview_offsets(lv, prev_lv), lv.nx, lv.ny)
+        for j in range(lv.ny):
+            for i in range(lv.nx):
+                if cur[j, i, ..., 3].any():
+                    ours[f"tile_{lv.zoom}_{lv.tminx + i}_{geo.xyz_row(lv.tmaxy - j, lv.zoom)}"] = cur[j, i]
+        prev, prev_lv = cur, lv
+    compare_with_gdal(g, ours)
