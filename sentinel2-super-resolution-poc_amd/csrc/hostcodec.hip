@@ -87,13 +87,22 @@ extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, 
     size_t pos = 0;
     uint64_t acc = 0;
     int nacc = 0;
-    auto put = [&](int code, int width) -> bool {
+    auto put = [&](int code, int width) -> bool {    // MSB-first; four bytes leave the accumulator at a time
         acc = (acc << width) | (uint32_t)code;
         nacc += width;
-        while (nacc >= 8) {
-            if (pos >= cap) return false;
-            dst[pos++] = (uint8_t)(acc >> (nacc - 8));
-            nacc -= 8;
+        if (nacc >= 32) {
+            if (cap - pos < 4) {                     // the tail of a tight buffer: byte by byte
+                while (nacc >= 8) {
+                    if (pos >= cap) return false;
+                    dst[pos++] = (uint8_t)(acc >> (nacc - 8));
+                    nacc -= 8;
+                }
+                return true;
+            }
+            const uint32_t v = __builtin_bswap32((uint32_t)(acc >> (nacc - 32)));
+            memcpy(dst + pos, &v, 4);
+            pos += 4;
+            nacc -= 32;
         }
         return true;
     };
@@ -131,6 +140,11 @@ extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, 
         if (next == 4094) { if (!put(256, width)) return S2SR_E_CAPACITY; width = 9; }
         else if (next > (1 << width) - 1) ++width;
         if (!put(257, width)) return S2SR_E_CAPACITY;
+    }
+    while (nacc >= 8) {
+        if (pos >= cap) return S2SR_E_CAPACITY;
+        dst[pos++] = (uint8_t)(acc >> (nacc - 8));
+        nacc -= 8;
     }
     if (nacc > 0) {
         if (pos >= cap) return S2SR_E_CAPACITY;
