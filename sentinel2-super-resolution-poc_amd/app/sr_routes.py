@@ -57,11 +57,16 @@ class GpuAdmission:
     post-process resolve to, app.cnn_super_resolution.thread_device).  All state sits behind one lock --
     the reference mutates its set/deque from request and worker threads unguarded."""
 
-    def __init__(self, devices: List[int]):
+    def __init__(self, devices: List[int], jobs_per_device: int = 1):
+        """jobs_per_device: slots per GPU.  1 is the reference's shape (one job in flight); with 2 the host stages of one job
+        (GeoTIFF read, LZW / PNG encoders, file writes: ~30 of a 1024x1024 job's 84 ms) run while the other job has the device
+        (a handle serialises its own calls; tools/bench_jobs_inflight.py measures what that buys)."""
         if not devices:
             raise ValueError("GpuAdmission needs at least one device ordinal")
+        if jobs_per_device < 1:
+            raise ValueError("jobs_per_device must be at least 1")
         self.devices = list(devices)
-        self._free = deque(self.devices)
+        self._free = deque(d for _ in range(jobs_per_device) for d in self.devices)      # round-robin over the GPUs first
         self._busy = {}                  # job_id -> device
         self._pending = deque()          # (job_id, run) in arrival order
         self._lock = threading.Lock()
@@ -121,12 +126,12 @@ def _parse_multipart(content_type: str, body: bytes) -> dict:
 
 def create_app(data_dir: Path, source_dir: Optional[Path] = None, fetcher: Optional[Callable] = None, tiler=None,
                tile_min_zoom: int = 10, tile_max_zoom: int = 16, devices: Optional[List[int]] = None,
-               max_upload_bytes: int = MAX_UPLOAD_BYTES) -> FastAPI:
+               max_upload_bytes: int = MAX_UPLOAD_BYTES, jobs_per_device: int = 1) -> FastAPI:
     app = FastAPI(title="s2sr SR handler harness")
     if devices is None:
         import os
         devices = [int(os.environ.get("LOCAL_RANK", "0"))]      # one process per GPU: this process's GPU
-    admission = GpuAdmission(devices)
+    admission = GpuAdmission(devices, jobs_per_device)
     app.state.admission = admission
     data_dir = Path(data_dir)
     source_dir = Path(source_dir) if source_dir else data_dir / "source"

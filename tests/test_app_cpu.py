@@ -234,3 +234,9 @@ def test_gpu_admission_two_devices():
     assert adm.snapshot() == {"devices": [0, 1], "active": {}, "pending": []}
     with pytest.raises(ValueError):
         GpuAdmission([])
+    # two slots per GPU: four jobs are admitted at once, devices taken round-robin, the fifth queues
+    adm2 = GpuAdmission([0, 1], jobs_per_device=2)
+    got = [adm2.submit(f"j{i}", lambda dev: None) for i in range(5)]
+    assert got == [0, 1, 0, 1, None] and adm2.snapshot()["pending"] == ["j4"]
+    with pytest.raises(ValueError):
+        GpuAdmission([0], jobs_per_device=0)
