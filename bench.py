@@ -535,31 +535,36 @@ def main():
     # communication stream under chunk k+1's compute, stitched band by band and landed in a page-locked host image
     # (s2sr.dist.enhance_distributed).  Timed: host image in -> host image out on rank 0, barrier to barrier, max over ranks.
     if dist is not None and not a.no_secondary:
-        from s2sr.dist import NativeBackend, enhance_distributed
-        be = NativeBackend(eng, local)
-        img = aoi_image(aoi_n)
-        st = {}
-        for _ in range(2):                       # first sighting of every chunk (direct launches), then the graph captures
-            enhance_distributed(be, img, 256, 10, dst=0)
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        out = enhance_distributed(be, img, 256, 10, dst=0, stats=st)
-        torch.cuda.synchronize()
-        barrier()
-        dta = time.perf_counter() - t0
-        t = torch.tensor([dta], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dta = float(t.item())
-        if rank == 0:
-            line["aoi_strong_scaling"] = {
-                "value": round(16 * aoi_n * aoi_n / 1e6 / dta, 1), "unit": "SR-MP/s", "seconds": round(dta, 4), "n_gpus": world, "scaling": "strong",
-                "workload": f"configs[2]: ONE {aoi_n}x{aoi_n}x3 u8 host image (every rank holds it) -> {4 * aoi_n}x{4 * aoi_n} u8 page-locked host image on rank 0, "
-                            f"reference plan 256/10: {st.get('windows')} windows of 276x276 in contiguous blocks of {st.get('per_rank')} per rank, chunks {st.get('chunks')} "
-                            f"windows; gather to rank 0 per chunk on a communication stream, {st.get('bands')} bands stitched and copied out as they complete",
-                "rccl_ranks_seen": dist.get_world_size(), "collective_backend": backend,
-                "check": "bytes equal s2sr_enhance_u8 on one GPU (tests/test_gpu_net.py test_dist_aoi_chunked_equals_enhance)"}
-        del out, img
+        try:
+            from s2sr.dist import NativeBackend, enhance_distributed
+            be = NativeBackend(eng, local)
+            img = aoi_image(aoi_n)
+            st = {}
+            for _ in range(2):                       # first sighting of every chunk (direct launches), then the graph captures
+                enhance_distributed(be, img, 256, 10, dst=0)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            out = enhance_distributed(be, img, 256, 10, dst=0, stats=st)
+            torch.cuda.synchronize()
+            barrier()
+            dta = time.perf_counter() - t0
+            t = torch.tensor([dta], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dta = float(t.item())
+            if rank == 0:
+                line["aoi_strong_scaling"] = {
+                    "value": round(16 * aoi_n * aoi_n / 1e6 / dta, 1), "unit": "SR-MP/s", "seconds": round(dta, 4), "n_gpus": world, "scaling": "strong",
+                    "workload": f"configs[2]: ONE {aoi_n}x{aoi_n}x3 u8 host image (every rank holds it) -> {4 * aoi_n}x{4 * aoi_n} u8 page-locked host image on rank 0, "
+                                f"reference plan 256/10: {st.get('windows')} windows of 276x276 in contiguous blocks of {st.get('per_rank')} per rank, chunks {st.get('chunks')} "
+                                f"windows; gather to rank 0 per chunk on a communication stream, {st.get('bands')} bands stitched and copied out as they complete",
+                    "rccl_ranks_seen": dist.get_world_size(), "collective_backend": backend,
+                    "check": "bytes equal s2sr_enhance_u8 on one GPU (tests/test_gpu_net.py test_dist_aoi_chunked_equals_enhance)"}
+            del out, img
+        except Exception as e:      # noqa: BLE001 -- a failure every rank shares (planning, shapes) must not cost the headline; a one-sided
+            # failure inside a collective cannot be caught here: the process group's timeout ends such a run
+            if rank == 0:
+                line["aoi_strong_scaling"] = {"error": f"{type(e).__name__}: {e}", "n_gpus": world}
 
     # ---- behind the headline, same process, one GPU only: the fp8 line, the paths /api/wow really takes, one tile's latency
     if world == 1 and not a.no_secondary:
