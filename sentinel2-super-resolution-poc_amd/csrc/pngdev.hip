@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -372,21 +374,84 @@ int host_threads() {
     return n;
 }
 
-template <class F> void parallel_for(int n, F&& body) {      // body(i) for i in [0, n), dynamic chunks of 16
-    const int nt = std::min(host_threads(), (n + 15) / 16);
-    std::atomic<int> next{0};
-    auto work = [&]() {
+// Host threads that stay: a pyramid makes ~40 parallel_for calls, and a thread per call and worker was 1200 thread starts per
+// pyramid -- and, on a 256-thread host, as many malloc arenas as glibc allows for short-lived threads to park freed memory in
+// (the 15-minute soak's host RSS crept 0.5 MB/s).  One parallel_for runs at a time (callers from several handles take turns); the
+// calling thread works too.
+class HostPool {
+    std::vector<std::thread> threads_;
+    std::mutex mu_, serial_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(int)>* body_ = nullptr;
+    int n_ = 0, active_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+
+    void drain() {
         for (;;) {
-            const int i0 = next.fetch_add(16);
-            if (i0 >= n) return;
-            for (int i = i0; i < std::min(n, i0 + 16); ++i) body(i);
+            const int i0 = next_.fetch_add(16);
+            if (i0 >= n_) return;
+            for (int i = i0; i < std::min(n_, i0 + 16); ++i) (*body_)(i);
         }
-    };
-    if (nt <= 1) { work(); return; }
-    std::vector<std::thread> th;
-    for (int k = 1; k < nt; ++k) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
+    }
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            lk.unlock();
+            drain();
+            lk.lock();
+            if (--active_ == 0) cv_done_.notify_one();
+        }
+    }
+
+public:
+    explicit HostPool(int nthreads) {
+        for (int k = 1; k < nthreads; ++k) threads_.emplace_back([this] { worker(); });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    void run(int n, const std::function<void(int)>& body) {
+        if (n <= 0) return;
+        if (n <= 16 || threads_.empty()) {
+            for (int i = 0; i < n; ++i) body(i);
+            return;
+        }
+        std::lock_guard<std::mutex> one_at_a_time(serial_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            body_ = &body;
+            n_ = n;
+            next_.store(0);
+            active_ = (int)threads_.size();
+            ++generation_;
+        }
+        cv_work_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return active_ == 0; });
+        body_ = nullptr;
+    }
+};
+
+HostPool& host_pool() {
+    static HostPool pool(host_threads());          // made at first use; a process that forks afterwards must not call in the child
+    return pool;
+}
+
+template <class F> void parallel_for(int n, F&& body) {      // body(i) for i in [0, n), dynamic chunks of 16
+    const std::function<void(int)> f(std::forward<F>(body));
+    host_pool().run(n, f);
 }
 
 }  // namespace
