@@ -189,6 +189,25 @@ int  s2sr_postprocess_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t 
 int  s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W,
                                    const s2sr_pp_params* prm, void* d_out, void* stream);
 
+/* The same post-process over ONE device-resident image in row bands, for callers whose image becomes complete band by band (an
+ * AOI's mosaic: the chunks of s2sr_enhance_u8, the gathers of s2sr/dist.py).  CLAHE's 8x8 grid spans the whole image
+ * (wow_sr.py:191-192), so no output row exists before every input row has been counted; the split lets the counting run under
+ * the compute of the windows still to come and the finishing overlap the copy out:
+ *   begin  geometry, constants and channel order of the image; zeroes the histograms (allocates: call it before queueing work)
+ *   hist   counts rows [y0, y1) of d_img ([H, W, 3] u8) -- any order, every row exactly once
+ *   lut    clip / redistribute / CDF once all rows are counted
+ *   rows   finishes rows [y0, y1) into the same rows of d_out ([H, W, 3]); bands follow each other from row 0; d_out may be d_img
+ *          (a band is rewritten only after the CLAHE pass, which runs a blur radius ahead, has read it)
+ * Same bytes as s2sr_postprocess_batch_u8_dev on the whole image.  order: S2SR_PP_ORDER_BGR = the bytes are B,G,R (what
+ * RealESRGAN.enhance handles, wow_sr.py:85,94; the colour math is always RGB's); S2SR_PP_ORDER_SWAP_OUT = R and B exchanged in
+ * the rows written (the job's cvtColor BGR2RGB, wow_sr.py:103, folded into the last pass).  One banded run per handle at a time. */
+#define S2SR_PP_ORDER_BGR      1
+#define S2SR_PP_ORDER_SWAP_OUT 2
+int  s2sr_pp_band_begin_dev(s2sr_handle* h, int32_t H, int32_t W, const s2sr_pp_params* prm, int32_t order, void* stream);
+int  s2sr_pp_band_hist_dev(s2sr_handle* h, const void* d_img, int32_t y0, int32_t y1, void* stream);
+int  s2sr_pp_band_lut_dev(s2sr_handle* h, void* stream);
+int  s2sr_pp_band_rows_dev(s2sr_handle* h, const void* d_img, int32_t y0, int32_t y1, void* d_out, void* stream);
+
 /* ---- XYZ tile pyramid: the step after the path (reference server/app/tiling.py:102-186 shells out to
  * `gdalwarp -t_srs EPSG:3857 -r bilinear` and `gdal2tiles.py --xyz --resampling average`).  The geometry
  * (projection, tile bounds, footprints) is resolved by the caller into tables; tile arrays are
@@ -338,6 +357,15 @@ int  s2sr_debug_conv_trunk(s2sr_handle* h, const s2sr_debug_trunk_args* a);
  * trace[wg*24 + k] with s_memtime ticks for the first trace_wgs workgroups. */
 int  s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int32_t cin, int32_t cout,
                            int32_t iters, float* avg_us, uint64_t* trace, int32_t trace_wgs);
+
+/* diagnostic: what the matrix pipe sustains on THIS part at its power cap, for the roofline claim of the fp16 trunk kernel
+ * (csrc/ceiling.hip).  mode 0: a bare v_mfma_f32_32x32x16_f16 loop, operands in registers; 1: the same loop with its operands
+ * re-read from LDS at conv_trunk_f16's 0.75 KiB per MFMA; 2: + the LDS ring refilled by LDS-DMA at the kernel's 48 KiB per 288
+ * MFMAs from a 336-MB buffer (3-deep ring, counted vmcnt, one barrier per stage).  One workgroup per CU, random fp16 operands;
+ * `launches` back-to-back launches of `stages` stages per workgroup behind launches / 4 + 1 untimed ones; *ms_total = their
+ * time by HIP events, *flop_per_launch / *dma_bytes_per_launch = the work of one (28 stages = one conv1-4 launch of 16 images). */
+int  s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch,
+                             double* dma_bytes_per_launch, float* ms_total);
 
 #ifdef __cplusplus
 }

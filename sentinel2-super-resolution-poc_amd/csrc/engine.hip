@@ -172,6 +172,15 @@ struct s2sr_handle {
     size_t stitch_maps_cap = 0;
     int stitch_key[4] = {0, 0, 0, 0};
     hipEvent_t host_copy_ev = nullptr;          // s2sr_copy_to_host: orders the copy stream behind the caller's stream
+    bool ceiling_filled = false;                // s2sr_debug_mfma_ceiling: scratch[2] holds its operand data
+    // the banded post-process in progress on this handle (s2sr_pp_band_*_dev, enhance_impl): geometry, channel order, how far the
+    // CLAHE'd rows and the finished rows reach
+    struct PPBand {
+        bool open = false, lut = false;
+        int H = 0, W = 0, bgr = 0, swap_out = 0, radius = 0;
+        int applied_end = 0, rows_end = 0;
+        s2sr_pp_params prm{};
+    } ppb;
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     int64_t graph_replays = 0, graph_captures = 0;
@@ -1381,6 +1390,10 @@ int s2sr_debug_plan_chunks(int32_t units, int32_t u_max, int32_t unit_windows, i
 
 static int postprocess_dev_locked(s2sr_handle* h, const void* d_rgb, int32_t B, int32_t H, int32_t W, const s2sr_pp_params* prm,
                                   void* d_out, hipStream_t st);
+static int pp_band_begin_locked(s2sr_handle* h, int H, int W, const s2sr_pp_params* prm, int order, hipStream_t st);
+static int pp_band_hist_locked(s2sr_handle* h, const void* d_img, int y0, int y1, hipStream_t st);
+static int pp_band_lut_locked(s2sr_handle* h, hipStream_t st);
+static int pp_band_rows_locked(s2sr_handle* h, const void* d_img, int y0, int y1, void* d_out, hipStream_t st);
 
 // job_rgb: the caller's image is RGB and wants RGB back -- R and B are swapped on the device in front of and behind the net (the
 // reference's cvtColor pair, wow_sr.py:85,103).  prm: the crop-visibility post-process (wow_sr.py:187-209) on the stitched RGB
@@ -1503,9 +1516,23 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             chunk_r0.push_back(ny);
         }
         const int nchunks = (int)chunk_r0.size() - 1;
-        if (!out_f32 && nchunks > 1 && !whole_finish) {
+        if (!out_f32 && nchunks > 1) {
+            // A job (job_rgb / prm) takes the same route: the channel swap behind the net is applied to every band as it is stitched;
+            // the post-process -- image-global through CLAHE's grid (wow_sr.py:191-192) -- counts every band into the histograms as
+            // it is stitched (under the compute of the chunks still to come), builds the LUTs behind the last band and then
+            // finishes the image in row bands, each followed by its copy out: what is exposed behind the last window is one band's
+            // kernels plus the PCIe time of the image (the r04 form waited for the whole mosaic, swapped, post-processed and only
+            // then started the one copy).
             const size_t win_in = (size_t)wh * ww * 3, win_out = win_in * 16;
-            while ((int)h->group_done.size() < nchunks) {
+            const size_t row_b = (size_t)OW * 3;
+            int fin_rows = 0, nfin = 0;          // finishing bands of the post-process: ~48 MB each, whole 32-row tile rows
+            if (prm) {
+                fin_rows = (int)(((size_t)48 << 20) / row_b) & ~31;
+                if (fin_rows < 64) fin_rows = 64;
+                nfin = (OH + fin_rows - 1) / fin_rows;
+                if ((rc = pp_band_begin_locked(h, OH, OW, prm, job_rgb ? 3 : 0, st))) return rc;   // (allocates: before anything is enqueued)
+            }
+            while ((int)h->group_done.size() < nchunks + nfin) {
                 hipEvent_t e;
                 HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 h->group_done.push_back(e);
@@ -1521,21 +1548,44 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
                 int ye = OH;
                 if (r1 < ny)
                     for (ye = yb; ye < OH && rm[2 * ye] < r1; ++ye) {}
-                if (ye > yb)
+                if (ye > yb) {
                     HIPCHK(h, launch_stitch_u8((const uint8_t*)h->d_scratch[4], nx, wh * 4, ww * 4, d_rm + 2 * yb, d_cm, ye - yb, OW,
-                                               d_img_out + (size_t)yb * OW * 3, st));
+                                               d_img_out + (size_t)yb * row_b, st));
+                    if (prm) {
+                        if ((rc = pp_band_hist_locked(h, d_img_out, yb, ye, st))) return rc;
+                    } else if (job_rgb) {
+                        HIPCHK(h, launch_swap_rb_u8(d_img_out + (size_t)yb * row_b, (size_t)(ye - yb) * OW, d_img_out + (size_t)yb * row_b, st));
+                    }
+                }
                 HIPCHK(h, hipEventRecord(h->group_done[c], st));
-                if (c > 0 && prev_ye > prev_yb) {
+                if (!prm && c > 0 && prev_ye > prev_yb) {
                     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[c - 1], 0));
-                    if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                         (size_t)(prev_ye - prev_yb) * OW * 3, false))) return rc;
+                    if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * row_b, d_img_out + (size_t)prev_yb * row_b,
+                                         (size_t)(prev_ye - prev_yb) * row_b, false))) return rc;
                 }
                 prev_yb = yb; prev_ye = ye; yb = ye;
             }
-            if (prev_ye > prev_yb) {
-                HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks - 1], 0));
-                if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * OW * 3, d_img_out + (size_t)prev_yb * OW * 3,
-                                     (size_t)(prev_ye - prev_yb) * OW * 3, true))) return rc;
+            if (!prm) {
+                if (prev_ye > prev_yb) {
+                    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks - 1], 0));
+                    if ((rc = d2h_staged(h, out_u8 + (size_t)prev_yb * row_b, d_img_out + (size_t)prev_yb * row_b,
+                                         (size_t)(prev_ye - prev_yb) * row_b, true))) return rc;
+                }
+            } else {
+                // LUTs, then every finishing band's kernels (in place: a band's rows are rewritten only after the apply pass, which
+                // runs R rows ahead, has read them), an event behind each; the copies follow band by band on the copy stream
+                if ((rc = pp_band_lut_locked(h, st))) return rc;
+                for (int b = 0; b < nfin; ++b) {
+                    const int y0 = b * fin_rows, y1 = y0 + fin_rows < OH ? y0 + fin_rows : OH;
+                    if ((rc = pp_band_rows_locked(h, d_img_out, y0, y1, d_img_out, st))) return rc;
+                    HIPCHK(h, hipEventRecord(h->group_done[nchunks + b], st));
+                }
+                for (int b = 0; b < nfin; ++b) {
+                    const int y0 = b * fin_rows, y1 = y0 + fin_rows < OH ? y0 + fin_rows : OH;
+                    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks + b], 0));
+                    if ((rc = d2h_staged(h, out_u8 + (size_t)y0 * row_b, d_img_out + (size_t)y0 * row_b, (size_t)(y1 - y0) * row_b,
+                                         false))) return rc;
+                }
             }
             HIPCHK(h, hipStreamSynchronize(h->copy_stream));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -1687,6 +1737,84 @@ int s2sr_postprocess_batch_u8_dev(s2sr_handle* h, const void* d_rgb, int32_t B, 
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     return postprocess_dev_locked(h, d_rgb, B, H, W, prm, d_out, (hipStream_t)stream);   // NULL = the default stream, as everywhere in HIP
+}
+
+// ---- the post-process over one device image in row bands (see postprocess.hip launch_pp_band_*) -------------------------------
+// order: S2SR_PP_ORDER_BGR = the image's bytes are B,G,R; S2SR_PP_ORDER_SWAP_OUT = R and B exchanged in the rows written
+static int pp_band_begin_locked(s2sr_handle* h, int H, int W, const s2sr_pp_params* prm, int order, hipStream_t st) {
+    if (prm->clahe_grid <= 0 || prm->clahe_grid > 64) return fail(h, S2SR_E_INVALID, "clahe_grid must be 1..64");
+    int rc = ensure_scratch(h, 5, postprocess_work_bytes(1, H, W, *prm));
+    if (rc) return rc;
+    s2sr_handle::PPBand& b = h->ppb;
+    b = s2sr_handle::PPBand();
+    b.H = H; b.W = W; b.prm = *prm;
+    b.bgr = (order & S2SR_PP_ORDER_BGR) ? 1 : 0;
+    b.swap_out = (order & S2SR_PP_ORDER_SWAP_OUT) ? 1 : 0;
+    b.radius = pp_band_radius(*prm);
+    HIPCHK(h, launch_pp_band_begin(H, W, *prm, h->d_scratch[5], st));
+    b.open = true;
+    return S2SR_OK;
+}
+
+static int pp_band_hist_locked(s2sr_handle* h, const void* d_img, int y0, int y1, hipStream_t st) {
+    s2sr_handle::PPBand& b = h->ppb;
+    if (!b.open || b.lut) return fail(h, S2SR_E_INVALID, "pp_band_hist: no banded post-process open, or its LUTs are already built");
+    if (y0 < 0 || y1 > b.H || y0 > y1) return fail(h, S2SR_E_INVALID, "pp_band_hist: rows outside the image");
+    Scope sc(h, st, F_POST, 0.0, (double)(y1 - y0) * b.W * 3.0);
+    HIPCHK(h, launch_pp_band_hist((const uint8_t*)d_img, b.H, b.W, b.prm, b.bgr, y0, y1, h->d_scratch[5], st));
+    return S2SR_OK;
+}
+
+static int pp_band_lut_locked(s2sr_handle* h, hipStream_t st) {
+    s2sr_handle::PPBand& b = h->ppb;
+    if (!b.open || b.lut) return fail(h, S2SR_E_INVALID, "pp_band_lut: no banded post-process open, or its LUTs are already built");
+    HIPCHK(h, launch_pp_band_lut(b.H, b.W, b.prm, h->d_scratch[5], st));
+    b.lut = true;
+    return S2SR_OK;
+}
+
+static int pp_band_rows_locked(s2sr_handle* h, const void* d_img, int y0, int y1, void* d_out, hipStream_t st) {
+    s2sr_handle::PPBand& b = h->ppb;
+    if (!b.open || !b.lut) return fail(h, S2SR_E_INVALID, "pp_band_rows: the LUTs are not built (begin, hist over every row, lut, then rows)");
+    if (y0 != b.rows_end || y1 <= y0 || y1 > b.H) return fail(h, S2SR_E_INVALID, "pp_band_rows: bands must follow each other from row 0");
+    const int need = y1 + b.radius < b.H ? y1 + b.radius : b.H;     // the blur of row y1-1 reads R rows below it
+    Scope sc(h, st, F_POST, 0.0, (double)(y1 - y0) * b.W * 6.0);
+    if (need > b.applied_end) {
+        HIPCHK(h, launch_pp_band_apply((const uint8_t*)d_img, b.H, b.W, b.prm, b.bgr, b.applied_end, need, h->d_scratch[5], st));
+        b.applied_end = need;
+    }
+    HIPCHK(h, launch_pp_band_sharpen(b.H, b.W, b.prm, b.bgr, b.swap_out, y0, y1, h->d_scratch[5], (uint8_t*)d_out, st));
+    b.rows_end = y1;
+    if (y1 == b.H) b.open = false;
+    return S2SR_OK;
+}
+
+int s2sr_pp_band_begin_dev(s2sr_handle* h, int32_t H, int32_t W, const s2sr_pp_params* prm, int32_t order, void* stream) {
+    if (!h || !prm || H <= 0 || W <= 0) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pp_band_begin_locked(h, H, W, prm, order, (hipStream_t)stream);
+}
+
+int s2sr_pp_band_hist_dev(s2sr_handle* h, const void* d_img, int32_t y0, int32_t y1, void* stream) {
+    if (!h || !d_img) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pp_band_hist_locked(h, d_img, y0, y1, (hipStream_t)stream);
+}
+
+int s2sr_pp_band_lut_dev(s2sr_handle* h, void* stream) {
+    if (!h) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pp_band_lut_locked(h, (hipStream_t)stream);
+}
+
+int s2sr_pp_band_rows_dev(s2sr_handle* h, const void* d_img, int32_t y0, int32_t y1, void* d_out, void* stream) {
+    if (!h || !d_img || !d_out) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pp_band_rows_locked(h, d_img, y0, y1, d_out, (hipStream_t)stream);
 }
 
 // Host image in, host image out.  ONE lock scope from the upload to the download: the staging buffers
@@ -2084,6 +2212,39 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
     HIPCHK(h, hipMemcpyAsync(y, d_y, yb, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     dev_free(d_plane); dev_free(d_x); dev_free(d_y); dev_free(d_w); dev_free(d_b);
+    return S2SR_OK;
+}
+
+// diagnostic (bench.py secondary.mfma_ceiling): `launches` back-to-back launches of one of the three loops of ceiling.hip on one
+// workgroup per CU, timed with an event pair on the handle's stream behind launches / 4 + 1 untimed ones (the clock settles under load)
+int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch, double* dma_bytes_per_launch,
+                            float* ms_total) {
+    if (!h || mode < 0 || mode > 2 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+    const size_t src_bytes = (size_t)336 << 20;          // what a conv1-4 launch of 16 images fills its rings with; larger than L2 + MALL
+    const bool fresh = h->scratch_bytes[2] < src_bytes || !h->ceiling_filled;
+    int rc = ensure_scratch(h, 2, src_bytes);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(h, 3, (size_t)ncu * 512 * 4))) return rc;
+    hipStream_t st = h->stream;
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, fresh, (float*)h->d_scratch[3], ncu, stages, st));
+    h->ceiling_filled = true;
+    for (int i = 0; i < launches / 4; ++i)
+        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, st));
+    HIPCHK(h, hipEventRecord(e0, st));
+    for (int i = 0; i < launches; ++i)
+        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, st));
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
+    h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
+    h->ceiling_filled = false;                            // scratch[2] is anybody's again
+    if (flop_per_launch) *flop_per_launch = mfma_ceiling_flop_per_launch(ncu, stages);
+    if (dma_bytes_per_launch) *dma_bytes_per_launch = mode == 2 ? mfma_ceiling_dma_bytes_per_launch(ncu, stages) : 0.0;
     return S2SR_OK;
 }
 

@@ -220,6 +220,9 @@ struct ClaheGeom {
     int clip;        // absolute clip limit, 0 = off
     float lut_scale;
     int split;       // clahe_hist: workgroups (row bands) per CLAHE tile
+    // banded runs over ONE image (launch_pp_band_*): the kernels see rows [y0, y1) of it
+    int y0, y1;      // clahe_hist_rows: source rows counted; clahe_apply: y0 = image row of the first row handed over
+    int bgr;         // the image's bytes are B,G,R (what RealESRGAN.enhance handles, wow_sr.py:85,94); the colour math is RGB's
 };
 
 // ---- kernel 1: per-tile L histograms --------------------------------------------------------
@@ -251,6 +254,45 @@ __global__ void __launch_bounds__(256) clahe_hist_kernel(const uint8_t* __restri
     __syncthreads();
     const uint32_t v = sh[threadIdx.x];
     if (v) atomicAdd(&hist[((size_t)img * ntile + tile) * 256 + threadIdx.x], v);
+}
+
+// ---- kernel 1b: the same counts for the SOURCE rows [gm.y0, gm.y1) of one image ------------------
+// An AOI's mosaic is complete band by band (engine.hip enhance_impl, s2sr/dist.py); its histograms accumulate band by band under
+// the compute of the windows still to come.  A source row feeds the padded rows that map to it (itself, and its reflections in
+// the BORDER_REFLECT_101 padding), so the workgroups walk their CLAHE tile's padded rows and keep those whose source row is in
+// the band: integer counts, the same totals in any split.  grid.x = tile columns * split, grid.y = tile rows ty_lo..ty_hi.
+__global__ void __launch_bounds__(256) clahe_hist_rows_kernel(const uint8_t* __restrict__ img, ClaheGeom gm, int ty_lo,
+                                                              const PPTables* __restrict__ t, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t sh[256];
+    __shared__ PPTables s_t;
+    const int part = blockIdx.x % gm.split, tx = blockIdx.x / gm.split, ty = ty_lo + blockIdx.y;
+    const int rows_per = (gm.th + gm.split - 1) / gm.split;
+    const int r0 = part * rows_per, r1 = min(gm.th, r0 + rows_per);
+    // any row of this workgroup in the band?  (wave-uniform scan over at most th rows; most workgroups of a band leave here)
+    bool any = false;
+    for (int r = r0; r < r1 && !any; ++r) {
+        const int sy = reflect101(ty * gm.th + r, gm.H);
+        any = sy >= gm.y0 && sy < gm.y1;
+    }
+    if (!any) return;
+    sh[threadIdx.x] = 0;
+    t = stage_tables(t, &s_t);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const int sy = reflect101(ty * gm.th + r, gm.H);
+        if (sy < gm.y0 || sy >= gm.y1) continue;
+        const uint8_t* row = img + (size_t)sy * gm.W * 3;
+        for (int c = lane; c < gm.tw; c += 64) {
+            const int sx = reflect101(tx * gm.tw + c, gm.W);
+            const uint8_t* p = row + (size_t)sx * 3;
+            int L, A, B;
+            rgb2lab(t, p[gm.bgr ? 2 : 0], p[1], p[gm.bgr ? 0 : 2], L, A, B);
+            atomicAdd(&sh[L], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t v = sh[threadIdx.x];
+    if (v) atomicAdd(&hist[(size_t)(ty * gm.grid + tx) * 256 + threadIdx.x], v);
 }
 
 // ---- kernel 2: clip, redistribute, CDF -> LUT -----------------------------------------------
@@ -301,10 +343,10 @@ __global__ void __launch_bounds__(256) clahe_apply_kernel(const uint8_t* __restr
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int img = (int)(i / npx);
         const size_t rem = i - (size_t)img * npx;
-        const int y = (int)(rem / gm.W), x = (int)(rem % gm.W);
+        const int y = (int)(rem / gm.W) + gm.y0, x = (int)(rem % gm.W);
         const uint8_t* p = rgb + i * 3;
         int L, A, Bc;
-        rgb2lab(t, p[0], p[1], p[2], L, A, Bc);
+        rgb2lab(t, p[gm.bgr ? 2 : 0], p[1], p[gm.bgr ? 0 : 2], L, A, Bc);
         const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
         int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
         const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
@@ -319,9 +361,9 @@ __global__ void __launch_bounds__(256) clahe_apply_kernel(const uint8_t* __restr
         int r, g, b;
         lab2rgb(t, sat_round(res), A, Bc, r, g, b);
         uint8_t* o = out + i * 3;
-        o[0] = (uint8_t)r;
+        o[gm.bgr ? 2 : 0] = (uint8_t)r;
         o[1] = (uint8_t)g;
-        o[2] = (uint8_t)b;
+        o[gm.bgr ? 0 : 2] = (uint8_t)b;
     }
 }
 
@@ -375,7 +417,9 @@ __global__ void __launch_bounds__(256) clahe_apply4_kernel(const uint8_t* __rest
             const int bi = 3 * k;
             int r = (w[bi >> 2] >> (8 * (bi & 3))) & 255, g = (w[(bi + 1) >> 2] >> (8 * ((bi + 1) & 3))) & 255,
                 b = (w[(bi + 2) >> 2] >> (8 * ((bi + 2) & 3))) & 255;
-            if ((uint32_t)k < n) clahe_pixel(t, gm, lut + (size_t)img * gm.grid * gm.grid * 256, inv_tw, inv_th, (int)y, (int)x, r, g, b);
+            if (gm.bgr) { const int s_ = r; r = b; b = s_; }
+            if ((uint32_t)k < n) clahe_pixel(t, gm, lut + (size_t)img * gm.grid * gm.grid * 256, inv_tw, inv_th, (int)y + gm.y0, (int)x, r, g, b);
+            if (gm.bgr) { const int s_ = r; r = b; b = s_; }
             o[bi >> 2] |= (uint32_t)r << (8 * (bi & 3));
             o[(bi + 1) >> 2] |= (uint32_t)g << (8 * ((bi + 1) & 3));
             o[(bi + 2) >> 2] |= (uint32_t)b << (8 * ((bi + 2) & 3));
@@ -400,6 +444,11 @@ struct SharpParams {
     float w_img, w_blur;
     int do_veg, hue_lo, hue_hi;
     float sat_gain;
+    // banded runs over ONE image (launch_pp_band_sharpen): rows [y_begin, y_end) are produced, tile rows count from y_begin; the
+    // halo rows come from the same image (reflected at ITS borders), so a band's bytes are those of the whole-image launch
+    int y_begin, y_end;
+    int bgr;         // bytes are B,G,R: blur and weighted add are per channel, only the HSV step looks at the order
+    int swap_out;    // store R and B exchanged (the job's BGR2RGB, wow_sr.py:103, folded into the last pass)
 };
 
 __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restrict__ in, SharpParams sp,
@@ -408,7 +457,7 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
     __shared__ uint16_t s_h[(ST + 2 * MAXR) * ST * 3];
     __shared__ int32_t s_div[512];   // sdiv | hdiv180
     for (int i = threadIdx.x; i < 512; i += 256) s_div[i] = i < 256 ? t->sdiv[i] : t->hdiv180[i - 256];
-    const int tilesX = (sp.W + ST - 1) / ST, tilesY = (sp.H + ST - 1) / ST;
+    const int tilesX = (sp.W + ST - 1) / ST, tilesY = (sp.y_end - sp.y_begin + ST - 1) / ST;
     int id = blockIdx.x;
     const int tx = id % tilesX; id /= tilesX;
     const int ty = id % tilesY;
@@ -416,7 +465,7 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
     const uint8_t* src = in + (size_t)img * sp.H * sp.W * 3;
     uint8_t* dst = out + (size_t)img * sp.H * sp.W * 3;
     const int r = sp.radius, ext = ST + 2 * r;
-    const int y0 = ty * ST, x0 = tx * ST;
+    const int y0 = sp.y_begin + ty * ST, x0 = tx * ST;
     // stage the tile + halo (reflect-101 at the image border)
     for (int i = threadIdx.x; i < ext * ext; i += 256) {
         const int ly = i / ext, lx = i % ext;
@@ -442,7 +491,7 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
     for (int i = threadIdx.x; i < ST * ST; i += 256) {
         const int ly = i / ST, lx = i % ST;
         const int y = y0 + ly, x = x0 + lx;
-        if (y >= sp.H || x >= sp.W) continue;
+        if (y >= sp.y_end || x >= sp.W) continue;
         int px[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -456,21 +505,22 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel(const uint8_t* __restr
                 px[c] = center;
             }
         }
+        const int ir = sp.bgr ? 2 : 0, ib = 2 - ir;
         if (sp.do_veg) {
             int h, s, v;
-            rgb2hsv(s_div, px[0], px[1], px[2], h, s, v);
+            rgb2hsv(s_div, px[ir], px[1], px[ib], h, s, v);
             if (h > sp.hue_lo && h < sp.hue_hi) {
                 // float32 S*gain, clip to [0,255], astype(uint8) == truncation (wow_sr.py:204-207)
                 float fs = (float)s * sp.sat_gain;
                 fs = fminf(fmaxf(fs, 0.f), 255.f);
                 s = (int)fs;
             }
-            hsv2rgb(h, s, v, px[0], px[1], px[2]);
+            hsv2rgb(h, s, v, px[ir], px[1], px[ib]);
         }
         uint8_t* o = dst + ((size_t)y * sp.W + x) * 3;
-        o[0] = (uint8_t)px[0];
+        o[0] = (uint8_t)px[sp.swap_out ? 2 : 0];
         o[1] = (uint8_t)px[1];
-        o[2] = (uint8_t)px[2];
+        o[2] = (uint8_t)px[sp.swap_out ? 0 : 2];
     }
 }
 
@@ -489,14 +539,14 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel_r(const uint8_t* __res
     __shared__ __attribute__((aligned(16))) uint16_t s_h[3 * EH * SW];
     __shared__ int32_t s_div[512];   // sdiv | hdiv180
     for (int i = threadIdx.x; i < 512; i += 256) s_div[i] = i < 256 ? t->sdiv[i] : t->hdiv180[i - 256];
-    const int tilesX = (sp.W + SW - 1) / SW, tilesY = (sp.H + SH - 1) / SH;
+    const int tilesX = (sp.W + SW - 1) / SW, tilesY = (sp.y_end - sp.y_begin + SH - 1) / SH;
     int id = blockIdx.x;
     const int tx = id % tilesX; id /= tilesX;
     const int ty = id % tilesY;
     const int img = id / tilesY;
     const uint8_t* src = in + (size_t)img * sp.H * sp.W * 3;
     uint8_t* dst = out + (size_t)img * sp.H * sp.W * 3;
-    const int y0 = ty * SH, x0 = tx * SW;
+    const int y0 = sp.y_begin + ty * SH, x0 = tx * SW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (x0 - R >= 0 && x0 + SW - 1 + R < sp.W) {
         // interior in x: each staged row is EW*3 contiguous bytes of one image row
@@ -587,23 +637,24 @@ __global__ void __launch_bounds__(256) sharpen_veg_kernel_r(const uint8_t* __res
         const int y = y0 + 4 * yq + ry;
 #pragma unroll
         for (int xx = 0; xx < 2; ++xx) {
-            int px[3] = {res[ry][xx][0], res[ry][xx][1], res[ry][xx][2]};
+            int pr = res[ry][xx][sp.bgr ? 2 : 0], pg = res[ry][xx][1], pb = res[ry][xx][sp.bgr ? 0 : 2];
             if (sp.do_veg) {
                 int h, sa, v;
-                rgb2hsv(s_div, px[0], px[1], px[2], h, sa, v);
+                rgb2hsv(s_div, pr, pg, pb, h, sa, v);
                 if (h > sp.hue_lo && h < sp.hue_hi) {
                     float fs = (float)sa * sp.sat_gain;
                     fs = fminf(fmaxf(fs, 0.f), 255.f);
                     sa = (int)fs;
                 }
-                hsv2rgb(h, sa, v, px[0], px[1], px[2]);
+                hsv2rgb(h, sa, v, pr, pg, pb);
             }
             const int x = x0 + 2 * xp + xx;
-            if (y < sp.H && x < sp.W) {   // byte stores: measured faster than staging rows in LDS for dword stores
+            if (y < sp.y_end && x < sp.W) {   // byte stores: measured faster than staging rows in LDS for dword stores
                 uint8_t* o = dst + ((size_t)y * sp.W + x) * 3;
-                o[0] = (uint8_t)px[0];
-                o[1] = (uint8_t)px[1];
-                o[2] = (uint8_t)px[2];
+                const bool rfirst = (sp.bgr != 0) == (sp.swap_out != 0);   // R goes to byte 0 when the order ends up RGB
+                o[0] = (uint8_t)(rfirst ? pr : pb);
+                o[1] = (uint8_t)pg;
+                o[2] = (uint8_t)(rfirst ? pb : pr);
             }
         }
     }
@@ -697,6 +748,7 @@ hipError_t launch_postprocess(const uint8_t* d_rgb, int B, int H, int W, const s
     if (s2 || s3) {
         SharpParams sp{};
         sp.H = H; sp.W = W; sp.B = B;
+        sp.y_begin = 0; sp.y_end = H;
         sp.radius = 0;
         if (s2) gaussian_taps_q8(prm.blur_sigma, sp.radius, sp.taps);
         sp.w_img = prm.w_img; sp.w_blur = prm.w_blur;
@@ -712,6 +764,130 @@ hipError_t launch_postprocess(const uint8_t* d_rgb, int B, int H, int W, const s
         e = hipMemcpyAsync(d_out, d_rgb, (size_t)B * H * W * 3, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+// ---- the same post-process over ONE image in row bands ---------------------------------------------------------------------
+// CLAHE's grid is image-global (wow_sr.py:191-192): no output row exists before every input row has been counted.  A mosaic that
+// arrives band by band (the chunks of an AOI, engine.hip enhance_impl / s2sr/dist.py) therefore feeds the histograms as it arrives
+// (launch_pp_band_hist, under the compute of the windows still to come), and once the LUTs exist the image is finished band by
+// band (launch_pp_band_apply R rows ahead of launch_pp_band_sharpen), each band followed by its device-to-host copy, so what is
+// exposed behind the last window is one band's kernels plus the PCIe time of the image.  Same kernels, same bytes as
+// launch_postprocess on the whole image.  work: the layout of postprocess_work_bytes(1, H, W, prm) = hist | lut | CLAHE'd image.
+namespace {
+struct BandWork { uint32_t* hist; uint8_t* lut; uint8_t* tmp; };
+BandWork band_work(void* d_work, const s2sr_pp_params& prm) {
+    const size_t tiles = (size_t)prm.clahe_grid * prm.clahe_grid;
+    BandWork w;
+    w.hist = (uint32_t*)d_work;
+    w.lut = (uint8_t*)d_work + tiles * 256 * 4;
+    w.tmp = w.lut + ((tiles * 256 + 255) & ~(size_t)255);
+    return w;
+}
+}  // namespace
+
+int pp_band_radius(const s2sr_pp_params& prm) {
+    if (!(prm.stages & 2)) return 0;
+    int radius = 0, taps[2 * MAXR + 1];
+    gaussian_taps_q8(prm.blur_sigma, radius, taps);
+    return radius;
+}
+
+hipError_t launch_pp_band_begin(int H, int W, const s2sr_pp_params& prm, void* d_work, hipStream_t st) {
+    if (prm.clahe_grid <= 0 || prm.clahe_grid > 64 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+    if (!(prm.stages & 1)) return hipSuccess;
+    return hipMemsetAsync(d_work, 0, (size_t)prm.clahe_grid * prm.clahe_grid * 256 * 4, st);
+}
+
+hipError_t launch_pp_band_hist(const uint8_t* d_img, int H, int W, const s2sr_pp_params& prm, int bgr, int y0, int y1, void* d_work,
+                               hipStream_t st) {
+    if (y0 < 0 || y1 > H || y0 > y1) return hipErrorInvalidValue;
+    if (!(prm.stages & 1) || y0 == y1) return hipSuccess;
+    PPTables* t = nullptr;
+    hipError_t e = get_tables(&t);
+    if (e != hipSuccess) return e;
+    ClaheGeom g = clahe_geom(H, W, prm);
+    if (g.th <= 0 || g.tw <= 0) return hipErrorInvalidValue;
+    g.y0 = y0; g.y1 = y1; g.bgr = bgr;
+    // tile rows the band can reach: its own rows, and -- when it holds a row the bottom padding reflects -- every tile row below
+    // (the kernel checks row by row; tiny images whose padding bounces more than once take every tile row)
+    const int pad = g.eh - H;
+    int ty_lo = y0 / g.th, ty_hi = (y1 - 1) / g.th;
+    if (pad > 0 && (pad >= H || y1 > H - 1 - pad)) ty_hi = g.grid - 1;
+    if (pad >= H) ty_lo = 0;
+    // rows a tile row contributes to this band are at most min(th, y1 - y0): keep ~8 rows per wave and >= 512 workgroups when there are
+    const int rows = g.th < (y1 - y0) ? g.th : (y1 - y0);
+    g.split = rows >= 256 ? 8 : (rows >= 64 ? 4 : 1);
+    if (g.split > g.th) g.split = 1;
+    hipLaunchKernelGGL(clahe_hist_rows_kernel, dim3((unsigned)(g.grid * g.split), (unsigned)(ty_hi - ty_lo + 1)), dim3(256), 0, st, d_img, g,
+                       ty_lo, t, band_work(d_work, prm).hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_pp_band_lut(int H, int W, const s2sr_pp_params& prm, void* d_work, hipStream_t st) {
+    if (!(prm.stages & 1)) return hipSuccess;
+    ClaheGeom g = clahe_geom(H, W, prm);
+    if (g.th <= 0 || g.tw <= 0) return hipErrorInvalidValue;
+    const BandWork w = band_work(d_work, prm);
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3((unsigned)(prm.clahe_grid * prm.clahe_grid)), dim3(256), 0, st, w.hist, g, w.lut);
+    return hipGetLastError();
+}
+
+// rows [y0, y1) of d_img through the LUTs into the same rows of the work area's image
+hipError_t launch_pp_band_apply(const uint8_t* d_img, int H, int W, const s2sr_pp_params& prm, int bgr, int y0, int y1, void* d_work,
+                                hipStream_t st) {
+    if (y0 < 0 || y1 > H || y0 > y1) return hipErrorInvalidValue;
+    if (y0 == y1) return hipSuccess;
+    const BandWork w = band_work(d_work, prm);
+    const size_t off = (size_t)y0 * W * 3, nb = (size_t)(y1 - y0) * W * 3;
+    if (!(prm.stages & 1)) return hipMemcpyAsync(w.tmp + off, d_img + off, nb, hipMemcpyDeviceToDevice, st);
+    PPTables* t = nullptr;
+    hipError_t e = get_tables(&t);
+    if (e != hipSuccess) return e;
+    ClaheGeom g = clahe_geom(H, W, prm);
+    if (g.th <= 0 || g.tw <= 0) return hipErrorInvalidValue;
+    g.H = y1 - y0;                 // the kernels index the rows they were handed ...
+    g.y0 = y0; g.bgr = bgr;        // ... and place them in the grid of the whole image
+    const uint8_t* src = d_img + off;
+    uint8_t* dst = w.tmp + off;
+    const size_t total = (size_t)(y1 - y0) * W;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0 && total < (1ull << 32)) {
+        const size_t ng = (total + 3) / 4;
+        const unsigned grid4 = (unsigned)((ng + 255) / 256 > 2048 ? 2048 : (ng + 255) / 256);
+        hipLaunchKernelGGL(clahe_apply4_kernel, dim3(grid4), dim3(256), 0, st, src, g, 1, t, w.lut, dst);
+    } else {
+        const unsigned grid = (unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(clahe_apply_kernel, dim3(grid), dim3(256), 0, st, src, g, 1, t, w.lut, dst);
+    }
+    return hipGetLastError();
+}
+
+// rows [y0, y1) of the final image from the work area's image (whose rows [y0 - R, y1 + R) within the image must have been
+// applied) into the same rows of d_out ([H, W, 3]); swap_out: R and B exchanged on the way out
+hipError_t launch_pp_band_sharpen(int H, int W, const s2sr_pp_params& prm, int bgr, int swap_out, int y0, int y1, void* d_work,
+                                  uint8_t* d_out, hipStream_t st) {
+    if (y0 < 0 || y1 > H || y0 > y1) return hipErrorInvalidValue;
+    if (y0 == y1) return hipSuccess;
+    PPTables* t = nullptr;
+    hipError_t e = get_tables(&t);
+    if (e != hipSuccess) return e;
+    const BandWork w = band_work(d_work, prm);
+    SharpParams sp{};
+    sp.H = H; sp.W = W; sp.B = 1;
+    sp.y_begin = y0; sp.y_end = y1;
+    sp.bgr = bgr; sp.swap_out = swap_out;
+    sp.radius = 0;
+    if (prm.stages & 2) gaussian_taps_q8(prm.blur_sigma, sp.radius, sp.taps);
+    sp.w_img = prm.w_img; sp.w_blur = prm.w_blur;
+    sp.do_veg = (prm.stages & 4) ? 1 : 0; sp.hue_lo = prm.hue_lo; sp.hue_hi = prm.hue_hi; sp.sat_gain = prm.sat_gain;
+    const int rows = y1 - y0;
+    const unsigned grid = (unsigned)(((W + ST - 1) / ST) * ((rows + ST - 1) / ST));
+    const unsigned grid_r = (unsigned)(((W + SW - 1) / SW) * ((rows + SH - 1) / SH));
+    const size_t total_bytes = (size_t)H * W * 3;
+    if (sp.radius == 4) hipLaunchKernelGGL(sharpen_veg_kernel_r<4>, dim3(grid_r), dim3(256), 0, st, w.tmp, sp, total_bytes, t, d_out);
+    else if (sp.radius == 5) hipLaunchKernelGGL(sharpen_veg_kernel_r<5>, dim3(grid_r), dim3(256), 0, st, w.tmp, sp, total_bytes, t, d_out);
+    else if (sp.radius == 3) hipLaunchKernelGGL(sharpen_veg_kernel_r<3>, dim3(grid_r), dim3(256), 0, st, w.tmp, sp, total_bytes, t, d_out);
+    else hipLaunchKernelGGL(sharpen_veg_kernel, dim3(grid), dim3(256), 0, st, w.tmp, sp, t, d_out);   // radius 0: veg / copy only
     return hipGetLastError();
 }
 

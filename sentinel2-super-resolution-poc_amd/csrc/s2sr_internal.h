@@ -264,5 +264,22 @@ hipError_t launch_stitch_f32(const float* d_tiles /*[T,3,oth,otw]*/, int tilesX,
 hipError_t launch_postprocess(const uint8_t* d_rgb, int B, int H, int W, const s2sr_pp_params& prm, uint8_t* d_out,
                               void* d_work, size_t work_bytes, hipStream_t st);
 size_t postprocess_work_bytes(int B, int H, int W, const s2sr_pp_params& prm);
+// ... over ONE image in row bands (an AOI's mosaic arrives band by band; CLAHE's grid is image-global): histograms as the bands
+// arrive, LUTs once, then apply (R rows ahead) + sharpen band by band.  d_work = postprocess_work_bytes(1, H, W, prm) bytes; bgr:
+// the image's bytes are B,G,R; swap_out: R and B exchanged in the rows written.  Same bytes as launch_postprocess.
+int pp_band_radius(const s2sr_pp_params& prm);
+hipError_t launch_pp_band_begin(int H, int W, const s2sr_pp_params& prm, void* d_work, hipStream_t st);
+hipError_t launch_pp_band_hist(const uint8_t* d_img, int H, int W, const s2sr_pp_params& prm, int bgr, int y0, int y1, void* d_work,
+                               hipStream_t st);
+hipError_t launch_pp_band_lut(int H, int W, const s2sr_pp_params& prm, void* d_work, hipStream_t st);
+hipError_t launch_pp_band_apply(const uint8_t* d_img, int H, int W, const s2sr_pp_params& prm, int bgr, int y0, int y1, void* d_work,
+                                hipStream_t st);
+hipError_t launch_pp_band_sharpen(int H, int W, const s2sr_pp_params& prm, int bgr, int swap_out, int y0, int y1, void* d_work,
+                                  uint8_t* d_out, hipStream_t st);
+
+// measured MFMA ceilings (ceiling.hip): bare / LDS-fed / LDS-DMA-fed fp16 32x32x16 loops at conv_trunk_f16's operand traffic
+hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, hipStream_t st);
+double mfma_ceiling_flop_per_launch(int grid, int stages);
+double mfma_ceiling_dma_bytes_per_launch(int grid, int stages);
 
 }  // namespace s2sr

@@ -14,7 +14,11 @@ communication stream while chunk k+1 computes -- into views of ONE preallocated 
 windows' plan indices (no list of parts, no concatenation).  The consumer stitches every band of output rows as
 soon as the window rows that own it have arrived and lands it in a page-locked host array (`native.pinned_pool`)
 through `s2sr_copy_to_host`, so gather, stitch and device-to-host copy of everything but the last chunk hide under
-compute.
+compute.  With `enhance_crops` (the reference's default request, main.py:204,227) no finished row exists before the last
+window has arrived -- CLAHE's grid spans the mosaic (wow_sr.py:191-192) -- so the bands are counted into the CLAHE histograms
+as they are stitched (`s2sr_pp_band_hist_dev`, still under compute), the LUTs are built behind the last band, and the
+mosaic is finished in row bands that go to the host one behind the other: exposed are one band's kernels and the PCIe time
+of the image.  The mosaic stays BGR throughout (the kernels take the channel order as a flag; r04 flipped it twice).
 
 The compute backend is an object with the interface of `BackendBase`; `NativeBackend` is the product one
 (libs2sr.so on an MI355X, no fallback).  Tests drive the same orchestration over gloo with a numpy stand-in.
@@ -96,6 +100,26 @@ class BackendBase:
 
     def stitch_rows(self, tiles: torch.Tensor, H: int, W: int, tile: int, pad: int, y0: int, y1: int, img: torch.Tensor, stream=None) -> None:
         img[y0:y1] = self.stitch(tiles, H, W, tile, pad)[y0:y1]
+
+    # -- the image-global post-process over a BGR mosaic that completes band by band ---------------
+    # (defaults in terms of `postprocess` on the whole RGB image; NativeBackend: the s2sr_pp_band_*_dev calls)
+    def pp_begin(self, H: int, W: int, prm) -> None:
+        self._pp = {"H": H, "prm": prm, "counted": np.zeros(H, np.int32), "full": None}
+
+    def pp_hist_rows(self, img: torch.Tensor, y0: int, y1: int, stream=None) -> None:
+        self._pp["counted"][y0:y1] += 1
+
+    def pp_lut(self, stream=None) -> None:
+        assert (self._pp["counted"] == 1).all(), "every row of the mosaic is counted exactly once before the LUTs are built"
+
+    def pp_rows(self, img: torch.Tensor, y0: int, y1: int, out: torch.Tensor, stream=None) -> None:
+        if self._pp["full"] is None:          # (out may be img: take the result of the whole image before any row is rewritten)
+            self._pp["full"] = self.postprocess(img.flip(2).contiguous(), self._pp["prm"]).flip(2).contiguous()
+        out[y0:y1] = self._pp["full"][y0:y1]
+
+    def pp_band_rows(self, W: int) -> int:
+        """Rows per finishing band: ~48 MB, whole 32-row tile rows of the sharpen kernel."""
+        return max(64, ((48 << 20) // (3 * W)) & ~31)
 
     # -- host side ---------------------------------------------------------------------------
     def alloc_host(self, shape) -> np.ndarray:
@@ -185,6 +209,18 @@ class NativeBackend(BackendBase):
         self.engine.postprocess_batch_u8_dev(img.data_ptr(), 1, H, W, prm, out.data_ptr(), self._stream())
         return out
 
+    def pp_begin(self, H: int, W: int, prm) -> None:
+        self.engine.pp_band_begin_dev(H, W, prm, native.PP_ORDER_BGR, self._stream())
+
+    def pp_hist_rows(self, img, y0, y1, stream=None) -> None:
+        self.engine.pp_band_hist_dev(img.data_ptr(), y0, y1, self._stream(stream))
+
+    def pp_lut(self, stream=None) -> None:
+        self.engine.pp_band_lut_dev(self._stream(stream))
+
+    def pp_rows(self, img, y0, y1, out, stream=None) -> None:
+        self.engine.pp_band_rows_dev(img.data_ptr(), y0, y1, out.data_ptr(), self._stream(stream))
+
     def alloc_host(self, shape) -> np.ndarray:
         return native.pinned_pool.empty(shape, np.uint8)       # page-locked: every band lands with one DMA
 
@@ -244,12 +280,29 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
     x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.uint8)).to(dev)
     consumer = dst is None or rank == dst
 
+    def finish_rows(mosaic: torch.Tensor, stream=None) -> np.ndarray:
+        """LUTs, then the mosaic in row bands (in place), every band followed by its copy to the host.  Band b+1's kernels are
+        queued before the blocking copy of band b, so the copies run back to back."""
+        OH, OW, _ = mosaic.shape
+        out = backend.alloc_host((OH, OW, 3))
+        backend.pp_lut(stream)
+        step = backend.pp_band_rows(OW)
+        cuts = list(range(0, OH, step)) + [OH]
+        backend.pp_rows(mosaic, cuts[0], cuts[1], mosaic, stream)
+        for b in range(len(cuts) - 1):
+            if b + 2 < len(cuts):
+                backend.pp_rows(mosaic, cuts[b + 1], cuts[b + 2], mosaic, stream)
+            backend.to_host(out[cuts[b]:cuts[b + 1]], mosaic[cuts[b]:cuts[b + 1]], stream)
+        return out
+
     def finish_whole(mosaic: torch.Tensor) -> np.ndarray:
+        mosaic = mosaic.contiguous()
         if enhance_crops is not None:
-            rgb = mosaic.flip(2).contiguous()
-            mosaic = backend.postprocess(rgb, enhance_crops).flip(2).contiguous()
+            backend.pp_begin(mosaic.shape[0], mosaic.shape[1], enhance_crops)
+            backend.pp_hist_rows(mosaic, 0, mosaic.shape[0])
+            return finish_rows(mosaic)
         out = backend.alloc_host(tuple(mosaic.shape))
-        backend.to_host(out, mosaic.contiguous())
+        backend.to_host(out, mosaic)
         return out
 
     if H * W <= tile * tile * 4:
@@ -267,6 +320,9 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
     assert sum(chunks) == per and all(c > 0 for c in chunks), (chunks, per)
     if stats is not None:
         stats.update(windows=T, per_rank=per, chunks=list(chunks))
+    pp = consumer and enhance_crops is not None
+    if pp:
+        backend.pp_begin(4 * H, 4 * W, enhance_crops)     # (allocates its work area: before anything is queued)
     oshape = (4 * wh, 4 * ww, 3)
     mine = backend.cut(x, tile, pad, first, count, per, wh, ww)          # [per, wh, ww, 3], tail slots zero
     # ONE buffer for every window of the plan on a consumer, at the windows' plan indices (tail slots of the last ranks
@@ -317,6 +373,8 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
                 backend.stitch_rows(allbuf, H, W, tile, pad, y0, y1, image, comm)
                 if direct:
                     backend.to_host(out[y0:y1], image[y0:y1], comm)
+                else:
+                    backend.pp_hist_rows(image, y0, y1, comm)       # counted under the compute of the chunks still to come
                 nbands += 1
     if stats is not None:
         stats["bands"] = nbands
@@ -329,9 +387,10 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
         if comm is not None:
             comm.synchronize()
         return out
+    res = finish_rows(image, comm)                        # behind the last band's stitch and count, on the same stream
     if comm is not None:
-        backend.wait(None, backend.record(comm))          # the post-process runs on the compute stream, behind the last stitch
-    return finish_whole(image)
+        comm.synchronize()
+    return res
 
 
 def forward_batch_distributed(backend, tiles: np.ndarray) -> np.ndarray:

@@ -66,6 +66,9 @@ def pp_farm() -> PPParams:
     return PPParams(2.5, 8, 1.5, 2.2, -1.2, 35, 85, 1.3, 7)
 
 
+PP_ORDER_BGR, PP_ORDER_SWAP_OUT = 1, 2      # s2sr_pp_band_begin_dev `order` bits
+
+
 _lib = None
 
 _PROTOS = {
@@ -98,6 +101,10 @@ _PROTOS = {
     "s2sr_postprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_void_p]),
     "s2sr_postprocess_batch_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                 C.POINTER(PPParams), C.c_void_p, C.c_void_p]),
+    "s2sr_pp_band_begin_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PPParams), C.c_int32, C.c_void_p]),
+    "s2sr_pp_band_hist_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "s2sr_pp_band_lut_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "s2sr_pp_band_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "s2sr_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "s2sr_get_kernel_stats": (C.c_int, [C.c_void_p, C.POINTER(KStat), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_reset_kernel_stats": (C.c_int, [C.c_void_p]),
@@ -126,6 +133,8 @@ _PROTOS = {
     "s2sr_debug_plan_chunks": (C.c_int, [C.c_int32] * 6 + [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     "s2sr_debug_get_config": (C.c_int, [C.c_void_p, C.POINTER(DebugConfig)]),
     "s2sr_debug_conv_trunk": (C.c_int, [C.c_void_p, C.POINTER(DebugTrunkArgs)]),
+    "s2sr_debug_mfma_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_float)]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -551,6 +560,29 @@ class Engine:
     def postprocess_batch_u8_dev(self, d_in: int, B: int, H: int, W: int, prm: PPParams, d_out: int, stream: int = 0):
         self._check(self._lib.s2sr_postprocess_batch_u8_dev(self._h, d_in, B, H, W, C.byref(prm), d_out,
                                                             C.c_void_p(stream)), "s2sr_postprocess_batch_u8_dev")
+
+    # the same over ONE device image in row bands (include/s2sr.h: begin, hist over every row, lut, rows from row 0 on)
+    def pp_band_begin_dev(self, H: int, W: int, prm: PPParams, order: int = 0, stream: int = 0):
+        self._check(self._lib.s2sr_pp_band_begin_dev(self._h, H, W, C.byref(prm), order, C.c_void_p(stream)), "s2sr_pp_band_begin_dev")
+
+    def pp_band_hist_dev(self, d_img: int, y0: int, y1: int, stream: int = 0):
+        self._check(self._lib.s2sr_pp_band_hist_dev(self._h, C.c_void_p(d_img), y0, y1, C.c_void_p(stream)), "s2sr_pp_band_hist_dev")
+
+    def pp_band_lut_dev(self, stream: int = 0):
+        self._check(self._lib.s2sr_pp_band_lut_dev(self._h, C.c_void_p(stream)), "s2sr_pp_band_lut_dev")
+
+    def pp_band_rows_dev(self, d_img: int, y0: int, y1: int, d_out: int, stream: int = 0):
+        self._check(self._lib.s2sr_pp_band_rows_dev(self._h, C.c_void_p(d_img), y0, y1, C.c_void_p(d_out), C.c_void_p(stream)),
+                    "s2sr_pp_band_rows_dev")
+
+    def mfma_ceiling(self, mode: int, stages: int, launches: int) -> dict:
+        """csrc/ceiling.hip: mode 0 bare MFMA loop, 1 + LDS operand reads, 2 + LDS-DMA ring refill -> TFLOP/s over `launches` launches."""
+        fl, by, ms = C.c_double(0), C.c_double(0), C.c_float(0)
+        self._check(self._lib.s2sr_debug_mfma_ceiling(self._h, mode, stages, launches, C.byref(fl), C.byref(by), C.byref(ms)),
+                    "s2sr_debug_mfma_ceiling")
+        return {"ms": float(ms.value), "launches": launches, "us_per_launch": float(ms.value) * 1e3 / launches,
+                "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                "dma_GB_per_s": by.value * launches / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0}
 
     # -- measurement ------------------------------------------------------------------------
     def set_profiling(self, every: int):

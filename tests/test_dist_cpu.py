@@ -28,7 +28,7 @@ def make_fake_backend():
 
     class FakeBackend(sd.BackendBase):
         device = torch.device("cpu")
-        calls = {"stitch_rows": 0, "to_host": 0}
+        calls = {"stitch_rows": 0, "to_host": 0, "pp_hist": 0, "pp_rows": 0}
 
         def cut(self, img, tile, pad, first, count, slots, wh, ww):
             H, W, _ = img.shape
@@ -50,8 +50,33 @@ def make_fake_backend():
                 n += 1
             return sizes
 
+        # Stand-in for the image-global post-process (RGB in, RGB out): every output byte depends on a statistic of the WHOLE
+        # image (like CLAHE's histograms) and on the channel order.  The band-wise route accumulates the statistic band by band
+        # as the mosaic is stitched and finishes the rows in place; a band counted twice, a band missed, rows finished before the
+        # last band was counted or a channel flip gone wrong all change bytes.
+        MULT = torch.tensor([1, 2, 3], dtype=torch.int32)
+
         def postprocess(self, img, prm):
-            return 255 - img                 # stand-in for the image-global post-process
+            k = int(img.to(torch.int64).sum() % 251)
+            return ((img.to(torch.int32) * self.MULT + k) % 256).to(torch.uint8)
+
+        def pp_begin(self, H, W, prm):
+            super().pp_begin(H, W, prm)
+            self._sum = 0
+
+        def pp_hist_rows(self, img, y0, y1, stream=None):
+            self.calls["pp_hist"] += 1
+            super().pp_hist_rows(img, y0, y1, stream)
+            self._sum += int(img[y0:y1].to(torch.int64).sum())
+
+        def pp_rows(self, img, y0, y1, out, stream=None):
+            self.calls["pp_rows"] += 1
+            k = self._sum % 251
+            rgb = img[y0:y1].flip(2).to(torch.int32)
+            out[y0:y1] = ((rgb * self.MULT + k) % 256).to(torch.uint8).flip(2)
+
+        def pp_band_rows(self, W):
+            return 24                        # several finishing bands on the toy mosaics
 
         def stitch(self, tiles, H, W, tile, pad):
             wins = native.plan_tiles(H, W, tile, pad, 4)
@@ -103,6 +128,8 @@ def _worker(rank, world, port, cases, q):
     img = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
     g = sd.enhance_distributed(be, img, tile, pad, dst=world - 1, enhance_crops=object())
     assert (g is None) == (rank != world - 1)
+    if rank == world - 1:     # every stitched band was counted, and the mosaic left in several finishing bands
+        assert be.calls["pp_hist"] >= 2 and be.calls["pp_rows"] >= 2, be.calls
     st = {}
     n_rows = be.calls["stitch_rows"]
     g0 = sd.enhance_distributed(be, img, tile, pad, stats=st)        # the default: gather to rank 0, the job's one consumer
@@ -113,8 +140,16 @@ def _worker(rank, world, port, cases, q):
         assert st["bands"] >= 2 and be.calls["stitch_rows"] - n_rows == st["bands"], (st, be.calls)
     if rank == 0:
         assert np.array_equal(g0, res[0])
-    if rank == world - 1:
-        assert np.array_equal(g, (255 - res[0][:, :, ::-1])[:, :, ::-1])
+    if rank == world - 1:     # == the whole-image post-process of the finished (BGR) mosaic's RGB view
+        whole = be.postprocess(torch.from_numpy(np.ascontiguousarray(res[0][:, :, ::-1])), None).numpy()[:, :, ::-1]
+        assert np.array_equal(g, whole)
+        small = np.random.default_rng(7).integers(0, 256, (9, 11, 3), dtype=np.uint8)      # whole-image branch, same finish
+        gs = sd.enhance_distributed(be, small, tile, pad, dst=world - 1, enhance_crops=object())
+        es = be.postprocess(be.forward(torch.from_numpy(small).unsqueeze(0))[0].flip(2), None).flip(2).numpy()
+        assert np.array_equal(gs, es)
+    else:
+        small = np.random.default_rng(7).integers(0, 256, (9, 11, 3), dtype=np.uint8)
+        assert sd.enhance_distributed(be, small, tile, pad, dst=world - 1, enhance_crops=object()) is None
     blob = sd.broadcast_weights(synthetic_state_dict(1, seed=3) if rank == 0 else None, 1, torch.device("cpu")).numpy()
     ok_blob = np.array_equal(blob, flatten_state_dict(synthetic_state_dict(1, seed=3), 1))
     if rank == world - 1:      # the last rank (the one with the ragged tail) reports

@@ -398,7 +398,9 @@ def test_enhance_job_equals_the_separate_steps(monkeypatch, tmp_path):
     _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
     e = m.RealESRGAN(model_name="realesrgan_anime", tile_size=256)
     rng = np.random.default_rng(21)
-    for (H, W) in ((96, 130), (540, 610)):          # whole image; 3 x 3 windows of 276 with shifted edges
+    # whole image; 3 x 3 windows of 276 with shifted edges; 6 x 5 windows in several chunks: the band-wise finish (swap per band,
+    # histograms per band, the image finished and copied out in two finishing bands)
+    for (H, W) in ((96, 130), (540, 610), (1300, 1100)):
         rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
         rgb[..., 1] = np.maximum(rgb[..., 1], 90)
         sr_rgb = np.ascontiguousarray(e.enhance(np.ascontiguousarray(rgb[:, :, ::-1]))[:, :, ::-1])

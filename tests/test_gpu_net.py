@@ -999,6 +999,14 @@ def test_dist_aoi_chunked_equals_enhance():
             if (H, W) == (1300, 1100):
                 assert len(st["chunks"]) >= 2, st
             print(f"dist AOI {H}x{W} {tile}/{pad}: {st}")
+            # the reference's default request (enhance_crops=True, main.py:204,227): bands counted into the CLAHE histograms as
+            # they are stitched, finished band by band behind the last one -- the bytes of the job entry point (which swaps
+            # R and B around the net; the distributed path keeps the BGR mosaic and tells the kernels so)
+            want = e.enhance_job_u8(np.ascontiguousarray(img[:, :, ::-1]), native.pp_wow(), tile=tile, pad=pad)[:, :, ::-1]
+            with torch.cuda.stream(side):
+                got = enhance_distributed(be, img, tile, pad, dst=0, enhance_crops=native.pp_wow())
+            assert np.array_equal(got, want), (H, W, tile, pad, "enhance_crops")
+            assert np.array_equal(want, e.postprocess_u8(np.ascontiguousarray(exp[:, :, ::-1]), native.pp_wow())[:, :, ::-1])
         # a second call replays the chunk graphs the first two calls left (same buffers come back from the caching allocator is
         # NOT assumed: only that it runs and agrees)
         with torch.cuda.stream(side):

@@ -127,6 +127,72 @@ def test_full_pipelines_on_tiny_and_thin_images(eng):
             assert np.array_equal(got, fn(img)), shape
 
 
+def _banded(eng, img, prm, hist_cuts, row_cuts, order=0, in_place=False):
+    """The s2sr_pp_band_*_dev sequence on a device copy of `img`: hist over the bands of hist_cuts (given out of order on purpose),
+    lut, rows over the bands of row_cuts."""
+    import torch
+    H, W, _ = img.shape
+    x = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    y = x if in_place else torch.full_like(x, 0x5a)
+    st = torch.cuda.current_stream().cuda_stream
+    eng.pp_band_begin_dev(H, W, prm, order, st)
+    bands = list(zip(hist_cuts[:-1], hist_cuts[1:]))
+    for (a, b) in bands[1::2] + bands[0::2]:
+        eng.pp_band_hist_dev(x.data_ptr(), a, b, st)
+    eng.pp_band_lut_dev(st)
+    for a, b in zip(row_cuts[:-1], row_cuts[1:]):
+        eng.pp_band_rows_dev(x.data_ptr(), a, b, y.data_ptr(), st)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def test_banded_postprocess_gives_the_bytes_of_the_whole_image(eng):
+    """The band-wise route an AOI's mosaic takes (engine.hip enhance_impl, s2sr/dist.py: CLAHE histograms counted as the bands are
+    stitched, LUTs behind the last band, apply + sharpen band by band in front of the copy out) against the whole-image launch:
+    ragged sizes (both CLAHE paddings, the reflected rows counted into the last tile row from whichever band holds them), images
+    smaller than the grid (padding that bounces more than once), bands that are no multiple of any tile, one-row bands, in place,
+    BGR bytes and the swap on the way out, the farm constants, single stages."""
+    rng = np.random.default_rng(31)
+    P = native.PPParams
+    cases = [((257, 301), [0, 40, 41, 130, 200, 257], [0, 33, 100, 101, 257]),
+             ((256, 512), [0, 256], [0, 64, 128, 256]),
+             ((67, 101), [0, 10, 60, 67], [0, 67]),
+             ((131, 64), [0, 1, 2, 3, 120, 131], [0, 7, 14, 131]),
+             ((5, 9), [0, 2, 5], [0, 1, 5]),          # smaller than the 8x8 grid and than the blur radius
+             ((9, 17), [0, 9], [0, 4, 9]),
+             ((1, 40), [0, 1], [0, 1])]
+    for (H, W), hc, rc in cases:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[..., 1] = np.maximum(img[..., 1], 90)
+        for prm in (native.pp_wow(), native.pp_farm()):
+            want = eng.postprocess_u8(img, prm)
+            assert np.array_equal(_banded(eng, img, prm, hc, rc), want), (H, W, "rgb")
+            assert np.array_equal(_banded(eng, img, prm, hc, rc, in_place=True), want), (H, W, "in place")
+            bgr = np.ascontiguousarray(img[:, :, ::-1])
+            got = _banded(eng, bgr, prm, hc, rc, native.PP_ORDER_BGR, in_place=True)
+            assert np.array_equal(got[:, :, ::-1], want), (H, W, "bgr in, bgr out")
+            got = _banded(eng, bgr, prm, hc, rc, native.PP_ORDER_BGR | native.PP_ORDER_SWAP_OUT)
+            assert np.array_equal(got, want), (H, W, "bgr in, rgb out")
+            got = _banded(eng, img, prm, hc, rc, native.PP_ORDER_SWAP_OUT)
+            assert np.array_equal(got[:, :, ::-1], want), (H, W, "rgb in, bgr out")
+    img = rng.integers(0, 256, (150, 203, 3), dtype=np.uint8)
+    for stages in (1, 2, 3, 4, 5, 6):
+        prm = P(2.5, 8, 1.2, 1.4, -0.4, 35, 85, 1.2, stages)
+        assert np.array_equal(_banded(eng, img, prm, [0, 70, 150], [0, 31, 150], in_place=True), eng.postprocess_u8(img, prm)), stages
+    # misuse is refused, not computed: rows before the LUTs, bands out of order
+    import torch
+    x = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda")
+    eng.pp_band_begin_dev(64, 64, native.pp_wow(), 0, 0)
+    with pytest.raises(native.S2srError):
+        eng.pp_band_rows_dev(x.data_ptr(), 0, 32, x.data_ptr(), 0)
+    eng.pp_band_hist_dev(x.data_ptr(), 0, 64, 0)
+    eng.pp_band_lut_dev(0)
+    with pytest.raises(native.S2srError):
+        eng.pp_band_rows_dev(x.data_ptr(), 32, 64, x.data_ptr(), 0)
+    eng.pp_band_rows_dev(x.data_ptr(), 0, 64, x.data_ptr(), 0)
+    torch.cuda.synchronize()
+
+
 def test_gpu_against_cv2_golden(eng, golden_dir):
     """With tests/golden/g9_cv2_postprocess.npz present (tools/make_cv2_golden.py, run where cv2 is installed): the HIP
     post-process against OpenCV's own output of the reference's call chain, end to end, within 2 LSB per byte at >= 99 % of the

@@ -1,8 +1,10 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/prof_r04.sh <name>
+# usage (on the GPU box, from the repo root): GIT_REV=<rev> tools/prof_pmc.sh <name>
 #   -> gpurun_out/<name>/: rocprofv3 kernel-trace stats of `bench.py` (hp and fp8 lines) + separate PMC passes
 #      (one counter group per pass, as MI355X_MICROARCH.md prescribes) on one group of 16 tiles per mode,
-#      then tools/summarize_prof.py -> summary.txt and pmc_summary.json
+#      then tools/summarize_prof.py -> summary.txt and pmc_summary.json (stamped with GIT_REV: the box has no .git, so the
+#      caller passes `git rev-parse --short HEAD` -- tools/gpu_prof.sh does)
+export GIT_REV=${GIT_REV:-unknown}
 OUT=$PWD/gpurun_out/$1
 R=$PWD
 mkdir -p $OUT

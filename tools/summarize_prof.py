@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 csv output of tools/prof_r04.sh per kernel: kernel-trace stats per mode, PMC sums per
+"""Summarise rocprofv3 csv output of tools/prof_pmc.sh per kernel: kernel-trace stats per mode, PMC sums per
 dispatch, and profiles-ready pmc_summary.json (HBM bytes per image and launch of the RDB conv kernels:
 FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE, both reported in KiB)."""
 import csv
@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-IMGS = 16          # images per launch in the PMC runs (tools/prof_r04.sh: --batch 16 --group 16)
+IMGS = 16          # images per launch in the PMC runs (tools/prof_pmc.sh: --batch 16 --group 16)
 
 
 def short(n):
@@ -47,7 +47,7 @@ try:
     rev = os.environ.get("GIT_REV") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
 except Exception:
     rev = None
-summary = {"_meta": {"group": IMGS, "git_rev": rev, "tool": "tools/prof_r04.sh",
+summary = {"_meta": {"group": IMGS, "git_rev": rev, "tool": "tools/prof_pmc.sh",
                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on tools/quick_bench.py --batch 16 --group 16; "
                              "FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B); counter units KiB"}}
 FAM = {"hp": {"rdb_conv1-4": ("conv_trunk_f16<1, 8, 3, 0", 18874368), "rdb_conv5": ("conv_trunk_f16<2, 4, 4, 1", 41943040),
@@ -63,10 +63,20 @@ for mode, fams in FAM.items():
             continue
         fs = [sum(pmc[mode][k][c][i] for k in ks) for c in ("FETCH_SIZE", "WRITE_SIZE") for i in (0, 1)]
         fk, wk = fs[0] / fs[1], fs[2] / fs[3]
-        summary[("" if mode == "hp" else "fp8:") + fam] = {
+        ent = {
             "kernel": " + ".join(sorted(ks)), "dispatches": fs[1], "images_per_launch": IMGS, "fetch_kib_raw": round(fk),
             "write_kib": round(wk), "hbm_bytes_per_image": round((2 * fk + wk) * 1024 / IMGS),
             "algorithmic_bytes_per_image_mean": alg}
+        # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs) / (1024 SIMDs x the kernel's cycles); the
+        # kernel's cycles = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 -- the two counters come from different passes
+        def mean(c):
+            v = [pmc[mode][k][c] for k in ks if c in pmc[mode][k]]
+            return sum(x[0] for x in v) / max(sum(x[1] for x in v), 1) if v else None
+        busy, gui = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("GRBM_GUI_ACTIVE")
+        if busy and gui:
+            ent["mfma_busy"] = round(busy / (1024 * gui / 8), 4)
+            ent["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), per dispatch means of separate passes"
+        summary[("" if mode == "hp" else "fp8:") + fam] = ent
 json.dump(summary, open(f"{out}/pmc_summary.json", "w"), indent=1)
 print("== pmc_summary.json")
 print(json.dumps(summary, indent=1))
