@@ -340,7 +340,9 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
         glds16<TRACE>(j < G::PI ? sb_i : wb_i, loff[sl], lds0 + slot_off + (uint32_t)j * 1024);
     };
 
-    // ---- the loader wave (PROD): the whole workgroup's DMA schedule
+    // ---- the loader wave (PROD): the whole workgroup's DMA schedule                          [role-branch]
+    // (tests/test_abi_cpu.py moves the block between the [hidden-bias-requests] markers up to this line in a scratch copy -- r04's
+    // faulting placement -- and expects tools/check_asm_loads.py --cfg to report it)
     if (PROD && wave == 4) {
         uint32_t loffP[G::PI];                                   // my 16 bytes of slab piece j
 #pragma unroll
@@ -381,6 +383,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
     // 2 us prologue of a 7-8 us single-tile launch).  Inline asm: the compiler's own wait would drain the ring.
     // BEHIND the loader wave's branch: a hidden load whose destination is dead on some path lands in registers the compiler has
     // handed to something else there (the loader's DMA offsets: a memory fault, r04).
+    // [hidden-bias-requests begin]
     constexpr bool kEarly = S2SR_F16_EARLYBIAS != 0;
     uint32_t bias_l = 0;
     if (!kEarly && tid < CT * 32) ((float*)(smem + G::BIAS_OFF))[tid] = p.bias[tid];
@@ -395,6 +398,7 @@ __global__ void __launch_bounds__(PROD ? 320 : 256, 1) conv_trunk_f16(const Conv
                 bq[kBiasC ? ct : 0][g] = kAccV ? asm_load16v(a) : asm_load16(a);
             }
     }
+    // [hidden-bias-requests end]
 
     // ---- fragment addresses inside a slot: per-lane base + immediate
     uint32_t bbase[3];

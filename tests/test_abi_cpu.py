@@ -147,10 +147,57 @@ def test_hidden_asm_loads_are_not_touched_before_their_wait(tmp_path):
         asm = tmp_path / (src + ".s")
         subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
                         "--cuda-device-only", str(csrc / src), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
-        r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_loads.py"), str(asm)], capture_output=True, text=True)
+        # --cfg: + the control-flow rule (every path from a hidden load to its first vmcnt wait; test below)
+        r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_loads.py"), "--cfg", str(asm)], capture_output=True, text=True)
         assert r.returncode == 0 and "0 hazard(s)" in r.stdout, r.stdout[-2000:]
         if src == "conv_trunk.hip":      # the check has something to check (conv3x3.hip's hidden loads sat in the RDB epilogues: experimental library now)
             assert asm.read_text().count("global_load_dwordx2 a[") + asm.read_text().count("global_load_dwordx4 a[") > 0
+
+
+def test_hidden_asm_loads_on_side_paths_r04_fault_is_caught(tmp_path):
+    """The guard for r04's GPU fault (profiles/r04_latency_anatomy.txt section 3: inline-asm bias requests issued in front of the
+    loader wave's role branch; on the loader's side their destination registers were dead, the compiler handed them to DMA
+    offsets, the landing loads overwrote those -- an aborted GPU test).  tools/check_asm_loads.py --cfg follows every path of the
+    control-flow graph from each hidden load to the first vmcnt wait on that path and reports any touch of the destination on the
+    way; no counting, hence no false positives from infeasible paths.  Shown here to (a) pass on the experimental build of
+    conv_trunk.hip at HEAD (the loader-wave form exists only there) and (b) FIRE on r04's placement, rebuilt in a scratch copy by
+    moving the marked request block back in front of the role branch."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    csrc = REPO / "sentinel2-super-resolution-poc_amd" / "csrc"
+    work = tmp_path / "pkg" / "csrc"
+    work.mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    shutil.copy(REPO / "include" / "s2sr.h", tmp_path / "include" / "s2sr.h")
+    shutil.copy(csrc / "s2sr_internal.h", work / "s2sr_internal.h")
+    src = (csrc / "conv_trunk.hip").read_text()
+    b0, b1 = "    // [hidden-bias-requests begin]", "    // [hidden-bias-requests end]\n"
+    role = "    // ---- the loader wave (PROD): the whole workgroup's DMA schedule                          [role-branch]"
+    assert src.count(b0) == 1 and src.count(b1) == 1 and src.count(role) == 1 and src.index(role) < src.index(b0)
+    block = src[src.index(b0):src.index(b1) + len(b1)]
+    rest = src.replace(block, "")
+    old = rest[:rest.index(role)] + block + rest[rest.index(role):]
+
+    def hazards(text, name):
+        (work / "conv_trunk.hip").write_text(text)
+        asm = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-DS2SR_EXPERIMENTAL=1", "-S",
+                        "--cuda-device-only", str(work / "conv_trunk.hip"), "-o", str(asm)], check=True, stderr=subprocess.DEVNULL)
+        r = subprocess.run([sys.executable, str(REPO / "tools" / "check_asm_loads.py"), "--cfg", str(asm)], capture_output=True, text=True)
+        return r.returncode, r.stdout
+
+    rc, out = hazards(src, "head")
+    assert rc == 0 and "0 hazard(s)" in out, out[-2000:]
+    rc, out = hazards(old, "r04_placement")
+    assert rc == 1 and "with no vmcnt wait in between" in out, out[-2000:]
+    # ... in the loader-wave form (template argument PROD = 1: conv_trunk_f16<1, 8, 3, 0, false, 1, ...>), nowhere else
+    lines = [l for l in out.splitlines() if "touches" in l]
+    assert lines and all("conv_trunk_f16ILi1ELi8ELi3ELi0ELb0ELi1E" in l for l in lines), out[-2000:]
 
 
 def test_enhance_chunk_plan_properties():

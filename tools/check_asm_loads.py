@@ -107,11 +107,105 @@ def check(path, branches=False):
     return bad
 
 
+def _tokens(t):
+    return re.findall(r"(?<![0-9a-zA-Z_])(?:[av]\[\d+:\d+\]|[av]\d+)(?![0-9a-zA-Z_])", t)
+
+
+def check_cfg(path):
+    """The rule that can live in the test suite (r04's fault, profiles/r04_latency_anatomy.txt section 3): from every hidden
+    (inline-asm, register-destination) global load follow EVERY path of the kernel's control-flow graph -- fall-through, both sides
+    of each s_cbranch, the target of each s_branch, wherever the blocks sit in the file -- up to the first `s_waitcnt` on that
+    path that names vmcnt at all; no instruction on the way may touch the load's destination registers.  Nothing is counted, so
+    an infeasible path cannot make a counted wait look too weak (the false positives `--branches` can give): what is reported is
+    a register handed to something else while a load into it is certainly still allowed to be in flight.  r04: the bias requests sat
+    in front of the loader wave's role branch; on the loader's side their destinations were dead, the compiler reused them for
+    DMA offsets and the landing loads overwrote those."""
+    kernels, cur = [], None
+    in_asm = False
+    for ln, line in enumerate(open(path), 1):
+        t = line.strip()
+        if t.startswith("_Z") and ":" in t and not t.startswith("_ZZ"):
+            cur = {"name": t.split(":")[0], "ins": [], "labels": {}}
+            kernels.append(cur)
+            in_asm = False
+            continue
+        if cur is None:
+            continue
+        lab = re.fullmatch(r"(\.LBB\d+_\d+):.*", t)
+        if lab:
+            cur["labels"][lab.group(1)] = len(cur["ins"])
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        cur["ins"].append((ln, t.split(";")[0].strip(), in_asm))
+    bad = 0
+    for k in kernels:
+        ins, labels = k["ins"], k["labels"]
+
+        def hidden(i):
+            _, t, a = ins[i]
+            return a and t.startswith("global_load_dword") and "lds" not in t
+
+        def succ(i):
+            t = ins[i][1]
+            m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", t)
+            if m:
+                return [labels[m.group(1)]] if m.group(1) in labels else []
+            if t.startswith("s_endpgm") or t.startswith("s_setpc") or t.startswith("s_swappc"):
+                return []
+            out = [i + 1] if i + 1 < len(ins) else []
+            m = re.match(r"s_cbranch\w*\s+(\.LBB\d+_\d+)", t)
+            if m and m.group(1) in labels:
+                out.append(labels[m.group(1)])
+            return out
+
+        seen_reports = set()
+        for i0 in range(len(ins)):
+            if not hidden(i0):
+                continue
+            toks = _tokens(ins[i0][1])
+            dest = regs(toks[0]) if toks else set()
+            if not dest:
+                continue
+            stack, seen = list(succ(i0)), set()
+            while stack:
+                i = stack.pop()
+                if i in seen or i >= len(ins):
+                    continue
+                seen.add(i)
+                ln, t, _ = ins[i]
+                if "s_waitcnt" in t and "vmcnt(" in t:
+                    continue                         # the first vmcnt wait of this path: the counted rule (check) takes over from here
+                if not hidden(i):
+                    used = set()
+                    for tok in _tokens(t):
+                        used |= regs(tok)
+                    hit = used & dest
+                    if hit and (ln, ins[i0][0]) not in seen_reports:
+                        seen_reports.add((ln, ins[i0][0]))
+                        bad += 1
+                        print(f"{path}:{ln}: {k['name']}: `{t}` touches {sorted(hit)} on a path from the hidden load at line {ins[i0][0]} "
+                              f"(`{ins[i0][1]}`) with no vmcnt wait in between")
+                        continue
+                stack.extend(succ(i))
+    return bad
+
+
 if __name__ == "__main__":
     # --branches: also carry the loads in flight at a forward branch to its target block (finds a hidden load whose destination
     # is dead on a side path, e.g. a role branch -- but every statically possible path counts, feasible or not: the counted waits
     # of the ring are only right on the feasible ones, so this mode is for reading its report, not for the test suite)
+    # --cfg: additionally the control-flow rule (check_cfg): every path from a hidden load to its first vmcnt wait; no counting, so
+    # it is the one the test suite runs (tests/test_abi_cpu.py)
     br = "--branches" in sys.argv
-    n = sum(check(p, br) for p in sys.argv[1:] if p != "--branches")
+    cfg = "--cfg" in sys.argv
+    files = [p for p in sys.argv[1:] if not p.startswith("--")]
+    n = sum(check(p, br) for p in files) + (sum(check_cfg(p) for p in files) if cfg else 0)
     print(f"{n} hazard(s)")
     sys.exit(1 if n else 0)
