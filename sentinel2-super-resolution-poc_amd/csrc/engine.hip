@@ -168,9 +168,10 @@ struct s2sr_handle {
     bool mosaic_on = true;        // S2SR_MOSAIC=0: windows that are no multiple of the 32-pixel patch travel one per image (ConvParams::mos_*)
     // paste maps of the window plan last stitched through s2sr_stitch_rows_u8_dev (row map, column map), kept on the device:
     // an AOI is stitched band by band, the maps are uploaded once per (H, W, tile, pad)
-    int32_t* d_stitch_maps = nullptr;
-    size_t stitch_maps_cap = 0;
-    int stitch_key[4] = {0, 0, 0, 0};
+    // (a small LRU of map sets: a service that alternates AOI sizes neither re-uploads nor synchronises the device per job)
+    struct StitchMaps { int key[4] = {0, 0, 0, 0}; int32_t* d = nullptr; size_t cap = 0; uint64_t last_use = 0; };
+    StitchMaps stitch_sets[4];
+    uint64_t stitch_clock = 0;
     hipEvent_t host_copy_ev = nullptr;          // s2sr_copy_to_host: orders the copy stream behind the caller's stream
     bool ceiling_filled = false;                // s2sr_debug_mfma_ceiling: scratch[2] holds its operand data
     // the banded post-process in progress on this handle (s2sr_pp_band_*_dev, enhance_impl): geometry, channel order, how far the
@@ -977,7 +978,8 @@ void s2sr_destroy(s2sr_handle* h) {
         if (h->stage_buf[i]) host_free(h->stage_buf[i]);
         if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
     }
-    if (h->d_stitch_maps) dev_free(h->d_stitch_maps);
+    for (auto& m : h->stitch_sets)
+        if (m.d) dev_free(m.d);
     if (h->host_copy_ev) hipEventDestroy(h->host_copy_ev);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1673,23 +1675,41 @@ int s2sr_stitch_rows_u8_dev(s2sr_handle* h, const void* d_tiles, int32_t H, int3
     const int nx = (W + tile - 1) / tile, ny = (H + tile - 1) / tile;
     const int wh = wins[0].y2 - wins[0].y1, ww = wins[0].x2 - wins[0].x1;
     const size_t nrm = 2 * (size_t)(4 * H), ncm = 2 * (size_t)(4 * W);
-    if (h->stitch_key[0] != H || h->stitch_key[1] != W || h->stitch_key[2] != tile || h->stitch_key[3] != pad + 1) {
+    // the plan's paste maps: from the handle's LRU of map sets, or built and uploaded now.  A NEW set costs an allocation and a
+    // blocking upload on the handle's own stream -- nothing the caller has queued on ITS stream is waited for (r04: any key change
+    // synchronised the device under the process-wide gate, so the first band's stitch drained every compute chunk already queued
+    // and stalled the captures of other handles).  Only when all four sets are taken is the least recently used one recycled, and
+    // only then is the device synchronised: a stitch that still reads it may be in flight on a stream this library does not know.
+    const int key[4] = {H, W, tile, pad + 1};
+    s2sr_handle::StitchMaps* ms = nullptr;
+    for (auto& m : h->stitch_sets)
+        if (m.d && m.key[0] == key[0] && m.key[1] == key[1] && m.key[2] == key[2] && m.key[3] == key[3]) ms = &m;
+    if (!ms) {
+        for (auto& m : h->stitch_sets)
+            if (!m.d) { ms = &m; break; }
+        if (!ms) {
+            ms = &h->stitch_sets[0];
+            for (auto& m : h->stitch_sets)
+                if (m.last_use < ms->last_use) ms = &m;
+            HIPCHK(h, dev_sync());
+            if (ms->cap < (nrm + ncm) * 4) {
+                HIPCHK(h, dev_free(ms->d));
+                ms->d = nullptr; ms->cap = 0;
+            }
+        }
+        ms->key[0] = 0;                       // (invalid until the upload is through)
+        if (!ms->d) {
+            HIPCHK(h, dev_malloc(&ms->d, (nrm + ncm) * 4));
+            ms->cap = (nrm + ncm) * 4;
+        }
         std::vector<int32_t> rm, cm;
         build_stitch_maps(wins, nx, ny, 4 * H, 4 * W, rm, cm);
-        if (h->stitch_maps_cap < (nrm + ncm) * 4) {
-            HIPCHK(h, dev_sync());     // a stitch of the previous plan may still read the old maps
-            if (h->d_stitch_maps) HIPCHK(h, dev_free(h->d_stitch_maps));
-            h->d_stitch_maps = nullptr; h->stitch_maps_cap = 0; h->stitch_key[0] = 0;
-            HIPCHK(h, dev_malloc(&h->d_stitch_maps, (nrm + ncm) * 4));
-            h->stitch_maps_cap = (nrm + ncm) * 4;
-        } else {
-            HIPCHK(h, dev_sync());
-        }
-        HIPCHK(h, copy_blocking(h, h->d_stitch_maps, rm.data(), nrm * 4, hipMemcpyHostToDevice));
-        HIPCHK(h, copy_blocking(h, h->d_stitch_maps + nrm, cm.data(), ncm * 4, hipMemcpyHostToDevice));
-        h->stitch_key[0] = H; h->stitch_key[1] = W; h->stitch_key[2] = tile; h->stitch_key[3] = pad + 1;
+        HIPCHK(h, copy_blocking(h, ms->d, rm.data(), nrm * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, copy_blocking(h, ms->d + nrm, cm.data(), ncm * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < 4; ++i) ms->key[i] = key[i];
     }
-    const int32_t* d_rm = h->d_stitch_maps;
+    ms->last_use = ++h->stitch_clock;
+    const int32_t* d_rm = ms->d;
     const int32_t* d_cm = d_rm + nrm;
     HIPCHK(h, launch_stitch_u8((const uint8_t*)d_tiles, nx, wh * 4, ww * 4, d_rm + 2 * (size_t)oy0, d_cm, oy1 - oy0, 4 * W,
                                (uint8_t*)d_out + (size_t)oy0 * 4 * W * 3, st));
@@ -1958,6 +1978,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
     const size_t out_words = png_plan_tiles(n, stats.data(), stats.data() + (size_t)n * 512, stats.data() + (size_t)n * 1024, paths,
                                             (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &plan);
     T[2] = now();
+    if (plan.failed) return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)");
     const size_t tb_b = plan.tb.size() * 4, hdr_b = plan.hdr.size() * 4, meta_b = plan.meta.size();
     if ((rc = ensure_scratch(h, 3, tb_b + hdr_b + meta_b))) return rc;
     if ((rc = ensure_scratch(h, 4, (out_words + 1) * 4))) return rc;
@@ -2014,7 +2035,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
             const Batch& b = batches[k - 1];
             HIPCHK(h, hipEventSynchronize(h->stage_ev[(k - 1) & 1]));
             const uint32_t* words = (const uint32_t*)h->stage_buf[(k - 1) & 1];
-            png_parallel_for(b.t1 - b.t0, [&](int i) {
+            if (!png_parallel_for(b.t1 - b.t0, [&](int i) {
                 const int t = b.t0 + i;
                 if (plan.mode[t] != 1) return;
                 static thread_local std::vector<uint8_t> buf;
@@ -2022,13 +2043,13 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
                                          plan.adler[t], buf))
                     failed.store(1);
                 else if (written) written[t] = 1;
-            });
+            })) failed.store(1);
         }
     }
     T[4] = now();
     if (!host_tiles.empty()) {
         const size_t cap = s2sr_png_bound(256, 256, 4);
-        png_parallel_for((int)host_tiles.size(), [&](int k) {
+        if (!png_parallel_for((int)host_tiles.size(), [&](int k) {
             static thread_local std::vector<uint8_t> buf;
             buf.resize(cap);
             size_t len = 0;
@@ -2037,7 +2058,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
                 !png::write_file(paths[t], buf.data(), len))
                 failed.store(1);
             else if (written) written[t] = 1;
-        });
+        })) failed.store(1);
     }
     T[5] = now();
     if (timing)
@@ -2045,7 +2066,7 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
                 "streams (%.0f MB) back in batches + files %.1f, host-encoded tiles %.1f\n", n, host_tiles.size(), T[1] - T[0], T[2] - T[1],
                 T[3] - T[2], (double)out_words * 4 / 1e6, T[4] - T[3], T[5] - T[4]);
     h->tiles_slot = slot; h->tiles_nx = nx; h->tiles_ny = ny;      // the scratch requests above dropped the marker; the level is intact
-    if (failed.load()) return fail(h, S2SR_E_IO, "a tile file could not be written");
+    if (failed.load()) return fail(h, S2SR_E_IO, "a tile file could not be written (or an encoder thread ran out of memory)");
     return S2SR_OK;
 }
 

@@ -13,8 +13,11 @@
 //   host           chunk framing, CRC-32, file write, on threads.
 // Integer / byte work.  The first form of the two kernels (one THREAD walks one row byte by byte: walk_row, *_kernel without
 // "wave") is kept behind S2SR_PNG_ROW_THREADS as the check: both forms must write the same bytes (tests/test_gpu_tiles.py).
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -366,9 +369,31 @@ __global__ void __launch_bounds__(256) png_tile_emit_wave_kernel(const uint8_t* 
     }
 }
 
-int host_threads() {
-    int n = (int)std::thread::hardware_concurrency();
+// CPUs this process may really use: its affinity mask, capped by the cgroup quota (cpu.max) -- what s2sr/hostpool.py counts; a
+// container may see 256 logical CPUs and be allowed 16 of them, and a pool of 32 on such a box only adds context switches
+int usable_cpus() {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
     if (n <= 0) n = 4;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) {
+                const int c = (int)((quota + per - 1) / per);
+                if (c >= 1 && c < n) n = c;
+            }
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+int host_threads() {
+    int n = usable_cpus();
     if (const char* e = getenv("S2SR_HOST_THREADS")) { const int v = atoi(e); if (v > 0 && v < n) n = v; }
     else if (n > 32) n = 32;
     return n;
@@ -388,11 +413,20 @@ class HostPool {
     uint64_t generation_ = 0;
     bool stop_ = false;
 
+    std::atomic<bool> threw_{false};
+    const pid_t pid_ = getpid();          // the process the threads live in: a forked child has this object but none of them
+
     void drain() {
         for (;;) {
             const int i0 = next_.fetch_add(16);
             if (i0 >= n_) return;
-            for (int i = i0; i < std::min(n_, i0 + 16); ++i) (*body_)(i);
+            for (int i = i0; i < std::min(n_, i0 + 16); ++i) {
+                try {
+                    (*body_)(i);
+                } catch (...) {           // (bad_alloc from a buffer resize: reported by run(), never std::terminate in a worker)
+                    threw_.store(true);
+                }
+            }
         }
     }
     void worker() {
@@ -421,13 +455,22 @@ public:
         cv_work_.notify_all();
         for (auto& t : threads_) t.join();
     }
-    void run(int n, const std::function<void(int)>& body) {
-        if (n <= 0) return;
-        if (n <= 16 || threads_.empty()) {
-            for (int i = 0; i < n; ++i) body(i);
-            return;
+    // false: some body(i) threw (every other index still ran)
+    bool run(int n, const std::function<void(int)>& body) {
+        if (n <= 0) return true;
+        if (n <= 16 || threads_.empty() || getpid() != pid_) {      // small jobs, and a forked child (its pool threads do not exist), run inline
+            bool ok = true;
+            for (int i = 0; i < n; ++i) {
+                try {
+                    body(i);
+                } catch (...) {
+                    ok = false;
+                }
+            }
+            return ok;
         }
         std::lock_guard<std::mutex> one_at_a_time(serial_);
+        threw_.store(false);
         {
             std::lock_guard<std::mutex> lk(mu_);
             body_ = &body;
@@ -441,17 +484,18 @@ public:
         std::unique_lock<std::mutex> lk(mu_);
         cv_done_.wait(lk, [&] { return active_ == 0; });
         body_ = nullptr;
+        return !threw_.load();
     }
 };
 
 HostPool& host_pool() {
-    static HostPool pool(host_threads());          // made at first use; a process that forks afterwards must not call in the child
+    static HostPool pool(host_threads());          // made at first use; in a child forked afterwards run() works inline (no threads there)
     return pool;
 }
 
-template <class F> void parallel_for(int n, F&& body) {      // body(i) for i in [0, n), dynamic chunks of 16
+template <class F> bool parallel_for(int n, F&& body) {      // body(i) for i in [0, n), dynamic chunks of 16; false: a body threw
     const std::function<void(int)> f(std::forward<F>(body));
-    host_pool().run(n, f);
+    return host_pool().run(n, f);
 }
 
 }  // namespace
@@ -490,7 +534,7 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     plan->hdr.assign((size_t)n * 160, 0);
     plan->meta.assign((size_t)n * sizeof(TileMeta), 0);
     std::vector<uint32_t> words(n, 0);
-    parallel_for(n, [&](int t) {
+    plan->failed = !parallel_for(n, [&](int t) {
         TileMeta* m = (TileMeta*)plan->meta.data() + t;
         m->skip = 1;
         if (!paths[t] || (skip_transparent && !flags[t])) return;
@@ -565,6 +609,6 @@ bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t defla
     return png::write_file(path, buf.data(), buf.size());
 }
 
-void png_parallel_for(int n, const std::function<void(int)>& body) { parallel_for(n, body); }
+bool png_parallel_for(int n, const std::function<void(int)>& body) { return parallel_for(n, body); }
 
 }  // namespace s2sr

@@ -232,6 +232,7 @@ struct PngTilePlan {
     std::vector<uint64_t> eob_at, out_word;
     std::vector<uint32_t> tb, hdr;        // [n][512] token table, [n][160] block header words (what the emit kernel reads)
     std::vector<uint8_t> meta;            // [n] TileMeta (pngdev.hip)
+    bool failed = false;                  // a planning thread threw (out of memory): the plan is incomplete
 };
 hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, bool row_threads,
                                  hipStream_t st);
@@ -241,7 +242,7 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
                       bool skip_transparent, bool force_host, PngTilePlan* plan);
 bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t deflate_bytes, uint32_t eob, uint64_t eob_at, uint32_t adler,
                          std::vector<uint8_t>& buf);
-void png_parallel_for(int n, const std::function<void(int)>& body);
+bool png_parallel_for(int n, const std::function<void(int)>& body);   // false: a body threw (the other indices still ran)
 
 // data-movement kernels (pack.hip)
 hipError_t launch_pack_u8(const uint8_t* d_tiles, int N, int H, int W, char* blk, int Hp, int Wp, hipStream_t st);

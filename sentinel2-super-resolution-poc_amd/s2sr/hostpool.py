@@ -13,12 +13,34 @@ _POOL = None
 _PID = None
 
 
-def workers() -> int:
+def env_int(name: str, default: int) -> int:
+    """A positive integer from the environment; anything else (unset, malformed, <= 0) gives the default -- what the native side's
+    getenv / atoi handling does, so a typo in a knob never surfaces as a codec error in the middle of a job."""
+    try:
+        v = int(os.environ.get(name, ""))
+    except ValueError:
+        return default
+    return v if v > 0 else default
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: its affinity mask, capped by the cgroup quota (cpu.max: a container may see 256 logical
+    CPUs and be allowed 16 of them)."""
     try:
         n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         n = os.cpu_count() or 4
-    return max(2, min(int(os.environ.get("S2SR_HOST_THREADS", "32")), n))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def workers() -> int:
+    return max(2, min(env_int("S2SR_HOST_THREADS", 32), usable_cpus()))
 
 
 def pool() -> ThreadPoolExecutor:

@@ -112,7 +112,8 @@ def _dtype(bits: int, fmt: int, bo: str) -> np.dtype:
 
 
 def max_decoded_bytes() -> int:
-    return int(os.environ.get("S2SR_TIFF_MAX_BYTES", str(1 << 32)))
+    from .hostpool import env_int
+    return env_int("S2SR_TIFF_MAX_BYTES", 1 << 32)      # (a malformed value is ignored, not turned into a TiffError of the file)
 
 
 def read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:

@@ -251,6 +251,17 @@ def test_cut_forward_stitch_equals_enhance():
             for dst in (None, 0):
                 got = enhance_distributed(be, img, ts, tp, dst=dst)
                 assert np.array_equal(got, exp), (H, W, dst)
+        # a service that alternates AOI sizes: the plan's paste maps live in a 4-entry LRU on the handle (engine.hip
+        # s2sr_stitch_rows_u8_dev); six geometries taken in turn, twice, recycle entries while bands of the previous job may
+        # still be queued -- every mosaic must keep its bytes (and, with enhance_crops, the band-wise post-process its own)
+        geos = [(37, 45, 16, 2), (50, 41, 16, 2), (64, 65, 32, 4), (33, 70, 16, 3), (49, 48, 16, 2), (70, 36, 32, 2)]
+        imgs = [rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8) for (H, W, _, _) in geos]
+        exps = [e.enhance_u8(im, tile=ts, pad=tp) for im, (_, _, ts, tp) in zip(imgs, geos)]
+        for _ in range(2):
+            for im, ex, (H, W, ts, tp) in zip(imgs, exps, geos):
+                assert np.array_equal(enhance_distributed(be, im, ts, tp, dst=0), ex), (H, W)
+                want = e.postprocess_u8(np.ascontiguousarray(ex[:, :, ::-1]), native.pp_farm())[:, :, ::-1]
+                assert np.array_equal(enhance_distributed(be, im, ts, tp, dst=0, enhance_crops=native.pp_farm()), want), (H, W, "crops")
     finally:
         dist.destroy_process_group()
 

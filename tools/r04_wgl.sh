@@ -2,8 +2,8 @@
 # r04 A/B: fp16 conv1-4 with the weights from global memory (WGL) against the shipped form, same box
 R=$PWD; OUT=$R/gpurun_out/r04_wgl; mkdir -p $OUT
 timeout -k 10 300 python3 -m pytest tests/test_gpu_trunk.py -x -q -m gpu -k "whole_patch" > $OUT/t1.log 2>&1
-echo "[wgl] per-layer rc=$?"; tail -3 $OUT/t1.log
-[ $? -eq 0 ] || exit 1
+rc=$?; echo "[wgl] per-layer rc=$rc"; tail -3 $OUT/t1.log
+[ $rc -eq 0 ] || exit 1
 for rep in 1 2 3; do
   for v in 0 1; do
     echo "== S2SR_F16_WGL=$v rep $rep"
