@@ -298,17 +298,22 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
     out = {"note": "one workgroup per CU, 8 waves, random fp16 operands in (-1, 1); stages of 288 MFMAs / 216 ds_read_b128 / 48 KiB LDS-DMA per "
                    "workgroup as in conv_trunk_f16 conv1-4 (28 stages per workgroup = the MFMA work of one launch of 16 images); no epilogue, no stores",
            "stages_per_launch": 448}
-    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed")):
+    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (3, "lds_dma_fed_half_bytes"), (4, "lds_dma_fed_from_cache")):
         probe = eng.mfma_ceiling(mode, 448, 8)                         # settles the clock and sizes the timed run
-        launches = int(max(16, min(4000, 0.8e6 / max(probe["us_per_launch"], 1.0))))
+        launches = int(max(16, min(4000, (0.8e6 if mode <= 2 else 0.5e6) / max(probe["us_per_launch"], 1.0))))
         sampler = ClockSampler(device_index)
         sampler.start()
         r = eng.mfma_ceiling(mode, 448, launches)
         clocks = sampler.stop()
         leg = {"TFLOP_per_s": round(r["TFLOP_per_s"], 1), "frac_of_spec_peak": round(r["TFLOP_per_s"] / MFMA_F16_PEAK_TFLOPS, 4),
                "seconds": round(r["ms"] * 1e-3, 3), "launches": launches}
-        if mode == 2:
+        if mode >= 2:
             leg["lds_dma_GB_per_s"] = round(r["dma_GB_per_s"], 1)
+        if mode == 3:
+            leg["what"] = "lds_dma_fed with 24 KiB of LDS-DMA per 288 MFMAs: what a schedule that moved half the bytes per FLOP would be fed at"
+        if mode == 4:
+            leg["what"] = "lds_dma_fed (48 KiB) from a 7.5-MB source that stays in L2 / MALL: the LDS fill without the HBM side"
+
         if clocks:
             leg.update(sclk_mhz=clocks["sclk_mhz"], power_w=clocks["power_w"],
                        frac_of_peak_at_clock=round(r["TFLOP_per_s"] / (MFMA_F16_PEAK_TFLOPS * clocks["sclk_mhz"] / 2400.0), 4))

@@ -216,7 +216,9 @@ int  s2sr_pp_band_rows_dev(s2sr_handle* h, const void* d_img, int32_t y0, int32_
  *   `step`-th output pixel (step a power of two, (gh-1)*step >= OH-1); bilinear with edge replication,
  *   alpha = 255 inside the source raster.
  * base: tile pixel = rounded mean of the source pixels with alpha > 0 in columns col_lo..col_hi and
- *   rows row_lo..row_hi (tables of nx*256 and ny*256 entries, lo > hi = empty).
+ *   rows row_lo..row_hi (tables of nx*256 and ny*256 entries, lo > hi = empty).  rgba == NULL: the raster is the H x W output the
+ *   previous call on this handle -- s2sr_warp_bilinear_u8 -- produced, taken from its device copy (any other call in between
+ *   invalidates the copy -> S2SR_E_INVALID).
  * overview: parent pixel = rounded mean of the valid pixels of its 2x2 group in the child array;
  *   (ox, oy) = child-array tile coordinates of the first parent tile's north-west child (may be -1).
  *   child == NULL: the children are the level the previous base / overview call on this handle produced, taken from the
@@ -361,7 +363,8 @@ int  s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int3
 /* diagnostic: what the matrix pipe sustains on THIS part at its power cap, for the roofline claim of the fp16 trunk kernel
  * (csrc/ceiling.hip).  mode 0: a bare v_mfma_f32_32x32x16_f16 loop, operands in registers; 1: the same loop with its operands
  * re-read from LDS at conv_trunk_f16's 0.75 KiB per MFMA; 2: + the LDS ring refilled by LDS-DMA at the kernel's 48 KiB per 288
- * MFMAs from a 336-MB buffer (3-deep ring, counted vmcnt, one barrier per stage).  One workgroup per CU, random fp16 operands;
+ * MFMAs from a 336-MB buffer (3-deep ring, counted vmcnt, one barrier per stage); 3: as 2 with half the fill (24 KiB); 4: as 2 from
+ * an 8-MB source that stays in L2 / MALL (the fill without the HBM side).  One workgroup per CU, random fp16 operands;
  * `launches` back-to-back launches of `stages` stages per workgroup behind launches / 4 + 1 untimed ones; *ms_total = their
  * time by HIP events, *flop_per_launch / *dma_bytes_per_launch = the work of one (28 stages = one conv1-4 launch of 16 images). */
 int  s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch,

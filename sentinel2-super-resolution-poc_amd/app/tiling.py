@@ -74,7 +74,7 @@ def _engine_and_lock():
     dev = current_device_index()
     with _ENGINES_LOCK:
         if dev not in _ENGINES:
-            _ENGINES[dev] = (native.Engine(num_block=1, device=dev), threading.Lock())
+            _ENGINES[dev] = (native.Engine(num_block=1, device=dev), threading.RLock())
         return _ENGINES[dev]
 
 
@@ -149,11 +149,12 @@ def reproject_to_web_mercator(input_path: Path, output_path: Path, resample_meth
 LAST_STATS: dict = {}        # where the last process_raster_to_tiles / generate_xyz_tiles call spent its time (seconds; tools/bench_job.py)
 
 
-def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_zoom: int, max_zoom: int) -> None:
+def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_zoom: int, max_zoom: int, on_device: bool = False) -> None:
     """RGBA raster on the EPSG:3857 grid -> z/x/y.png files (deepest zoom from the raster, the others from their children).
     The levels never leave the device as pixels: each is computed from the previous one's device copy and its PNG files are encoded
     there (s2sr_tiles_write_png: token statistics and bit emission are kernels, the Huffman codes come from the host in between;
-    chunk framing, CRC and the file writes run on native host threads).  r04, same 12.8k-tile pyramid: levels fetched and deflated
+    chunk framing, CRC and the file writes run on native host threads).  on_device: `rgba` is what the caller's warp call just left on
+    the engine (the caller holds the engine's lock across both): the base level reads that copy.  r04, same 12.8k-tile pyramid: levels fetched and deflated
     by zlib on a Python pool 1.9 s -> native host encoder, one call per 8 tiles 0.6 s -> encoded on the device (this)."""
     import time
     h, w = rgba.shape[:2]
@@ -167,7 +168,7 @@ def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_z
         for lv in levels:
             t0 = time.perf_counter()
             if prev_lv is None:
-                eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h), fetch=False)
+                eng.tiles_base_u8(rgba, *tiles.plan_base(lv, place, w, h), fetch=False, on_device=on_device)
             else:
                 ox, oy = tiles.overview_offsets(lv, prev_lv)
                 eng.tiles_overview_u8((prev_lv.ny, prev_lv.nx), ox, oy, lv.nx, lv.ny, on_device=True, fetch=False)
@@ -225,37 +226,36 @@ def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 1
     rgb = rio._to_u8(arr[..., :3] if b >= 3 else np.repeat(arr[..., :1], 3, axis=2), 0.0)
     t1 = time.perf_counter()
     LAST_STATS["read"] = t1 - t0
-    side = None
-    if crs.epsg != 3857:
-        # the warped raster is written next to the input like the reference does (<stem>_3857.tif, :251-252),
-        # but the pyramid is cut from the array in hand, with the coverage mask of the warp as alpha
-        plan = tiles.plan_warp(w, h, place, crs)
-        t2 = time.perf_counter()
-        eng, lock = _engine_and_lock()
-        with lock:
+    side, err = None, []
+    eng, lock = _engine_and_lock()
+    with lock:                   # one pyramid chain at a time per engine; held from the warp to the base level that reads its device copy
+        if crs.epsg != 3857:
+            # the warped raster is written next to the input like the reference does (<stem>_3857.tif, :251-252),
+            # but the pyramid is cut from the array in hand, with the coverage mask of the warp as alpha
+            plan = tiles.plan_warp(w, h, place, crs)
+            t2 = time.perf_counter()
             rgba = eng.warp_bilinear_u8(rgb, plan.grid, plan.step, plan.out_h, plan.out_w)
-        t3 = time.perf_counter()
-        place = plan.placement
-        LAST_STATS.update(warp_plan=t2 - t1, warp_call=t3 - t2)
-        err = []
+            t3 = time.perf_counter()
+            place = plan.placement
+            LAST_STATS.update(warp_plan=t2 - t1, warp_call=t3 - t2)
 
-        def write_3857():            # next to the pyramid, not in front of it: its strips fill the CPUs the device calls leave idle
-            try:
-                rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
-                                      _mercator_tags(plan.placement))
-            except BaseException as e:      # noqa: BLE001 -- surfaced below: a failed writer fails the call
-                err.append(e)
-        side = threading.Thread(target=write_3857)
-        side.start()
-    else:
-        rgba = np.dstack([rgb, np.full((h, w), 255, np.uint8)])
-    t4 = time.perf_counter()
-    try:
-        _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom)
-    finally:
-        if side is not None:
-            side.join()
-    if side is not None and err:
+            def write_3857():            # next to the pyramid, not in front of it: its strips fill the CPUs the device calls leave idle
+                try:
+                    rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
+                                          _mercator_tags(plan.placement))
+                except BaseException as e:      # noqa: BLE001 -- surfaced below: a failed writer fails the call
+                    err.append(e)
+            side = threading.Thread(target=write_3857)
+            side.start()
+        else:
+            rgba = np.dstack([rgb, np.full((h, w), 255, np.uint8)])
+        t4 = time.perf_counter()
+        try:
+            _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom, on_device=side is not None)
+        finally:
+            if side is not None:
+                side.join()
+    if err:
         raise err[0]
     LAST_STATS["pyramid"] = time.perf_counter() - t4
     return create_tileset_metadata(tiles_dir, bounds_4326, min_zoom, max_zoom)

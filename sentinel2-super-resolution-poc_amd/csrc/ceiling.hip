@@ -9,6 +9,8 @@
 //   mode 1  lds       + the operand reads from LDS (0.75 KiB per MFMA)
 //   mode 2  lds+dma   + the LDS ring refilled by LDS-DMA from a buffer that streams from HBM (48 KiB per 288 MFMAs, 3-deep ring,
 //                     counted vmcnt + one barrier per stage like the kernel)
+//   mode 3            as 2 with half the fill (24 KiB per 288 MFMAs): what a schedule that moved half the bytes per FLOP would get
+//   mode 4            as 2 from an 8-MB source that stays in L2 / MALL: the LDS-DMA issue and fill without the HBM side
 // Random fp16 operands in (-1, 1) (toggle rates, and with them power, depend on the data).  Two waves per SIMD so that LDS latency
 // hides without hand scheduling: these are ceilings, the occupancy is free to choose.  Diagnostic entry; nothing of the product
 // calls it.
@@ -28,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int STAGE = 48 * 1024;     // LDS bytes of one pipeline stage (the kernel's 46 KiB rounded up to 6 KiB per wave)
 constexpr int RING = 3;              // stages in the ring (conv1-4 form: 3 x 46 KiB)
 constexpr int WAVES = 8;
-constexpr int PW = STAGE / 1024 / WAVES;       // LDS-DMA instructions per wave and stage
+constexpr int PW_FULL = STAGE / 1024 / WAVES;  // LDS-DMA instructions per wave and stage (48 KiB per stage)
 constexpr int STEPS = 12;            // per wave and stage: 12 steps of 3 MFMAs = 36 (x 8 waves = the kernel's 288 per stage)
 // ds_read_b128 per wave and stage: 27 = 0.75 per MFMA (12 B fragments, 15 A fragments)
 
@@ -50,7 +52,7 @@ __global__ void fill_random_f16(uint32_t* dst, size_t n_words) {
     }
 }
 
-template <int MODE>
+template <int MODE, int PW>        // MODE 0 bare, 1 + LDS reads, 2 + LDS-DMA of PW KiB per wave and stage
 __global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restrict__ src, uint32_t nchunks, float* __restrict__ sink, int stages) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -71,7 +73,7 @@ __global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restric
     // LDS-DMA of stage s: this wave's PW KiB of chunk (s * gridDim.x + blockIdx.x) % nchunks into ring slot s % RING
     auto dma = [&](int s, int p) {
         const uint32_t chunk = ((uint32_t)s * gridDim.x + blockIdx.x) % nchunks;
-        const uint32_t piece = (uint32_t)(wave * PW + p) * 1024;
+        const uint32_t piece = (uint32_t)(wave * PW_FULL + p) * 1024;
         glds16(src + (size_t)chunk * STAGE, piece + lane_off, (uint32_t)(s % RING) * STAGE + piece);
     };
     if (MODE == 2) {
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restric
             if (MODE >= 1) {
                 // next step's fragments while this step's MFMAs run: B every step, A 15 times per stage
                 // (27 distinct KiB of the stage's 48 per wave, starting at the wave's own pieces: nothing for the compiler to merge)
-                auto piece = [&](int k) { return slot + (((uint32_t)wave * PW + (uint32_t)k) % (STAGE / 1024)) * 1024 + lane_off; };
+                auto piece = [&](int k) { return slot + (((uint32_t)wave * PW_FULL + (uint32_t)k) % (STAGE / 1024)) * 1024 + lane_off; };
                 nb = lds16(smem, piece(rd++));
                 na0 = lds16(smem, piece(rd++));
                 if (st % 4 == 3) na1 = lds16(smem, piece(rd++));
@@ -124,26 +126,28 @@ namespace s2sr {
 // src: >= nchunks * 48 KiB of operand data (filled here on first use when `fill`), sink: gridDim * 512 floats.  Returns the
 // launch error; FLOP of one launch = grid * stages * 8 waves * 36 MFMAs * 32768.
 hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, hipStream_t st) {
-    if (mode < 0 || mode > 2 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 4 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
     if (fill) hipLaunchKernelGGL(fill_random_f16, dim3(2048), dim3(256), 0, st, (uint32_t*)d_src, src_bytes / 4);
-    const uint32_t nchunks = (uint32_t)(src_bytes / STAGE);
+    uint32_t nchunks = (uint32_t)(src_bytes / STAGE);
     const size_t lds = (size_t)RING * STAGE;
+    typedef void (*K)(const char*, uint32_t, float*, int);
+    static const K kern[5] = {mfma_ceiling_kernel<0, PW_FULL>, mfma_ceiling_kernel<1, PW_FULL>, mfma_ceiling_kernel<2, PW_FULL>,
+                              mfma_ceiling_kernel<2, PW_FULL / 2>, mfma_ceiling_kernel<2, PW_FULL>};
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        hipError_t e = hipFuncSetAttribute((const void*)mfma_ceiling_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_ceiling_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_ceiling_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_err = e;
+        for (int m = 0; m < 5 && attr_err == hipSuccess; ++m)
+            attr_err = hipFuncSetAttribute((const void*)kern[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) return attr_err;
-    if (mode == 0) hipLaunchKernelGGL(mfma_ceiling_kernel<0>, dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages);
-    else if (mode == 1) hipLaunchKernelGGL(mfma_ceiling_kernel<1>, dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages);
-    else hipLaunchKernelGGL(mfma_ceiling_kernel<2>, dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages);
+    if (mode == 4) nchunks = nchunks < 160 ? nchunks : 160;       // 7.5 MB of source: resident in L2 / MALL
+    hipLaunchKernelGGL(kern[mode], dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages);
     return hipGetLastError();
 }
 
 double mfma_ceiling_flop_per_launch(int grid, int stages) { return (double)grid * stages * WAVES * (3.0 * STEPS) * 32768.0; }
-double mfma_ceiling_dma_bytes_per_launch(int grid, int stages) { return (double)grid * stages * STAGE; }
+double mfma_ceiling_dma_bytes_per_launch(int mode, int grid, int stages) {
+    return mode < 2 ? 0.0 : (double)grid * stages * (mode == 3 ? STAGE / 2 : STAGE);
+}
 
 }  // namespace s2sr

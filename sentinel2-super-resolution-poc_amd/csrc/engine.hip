@@ -128,6 +128,7 @@ struct s2sr_handle {
     int capture_failures = 0;            // captures voided by a device-wide call of another runtime user; 3 -> graphs off
     int tiles_slot = -1;                 // scratch slot that still holds the tile level the last pyramid call produced (-1: none)
     int tiles_nx = 0, tiles_ny = 0;
+    int warp_slot = -1, warp_h = 0, warp_w = 0;   // ... and the RGBA raster the last warp produced (s2sr_tiles_base_u8 with rgba == NULL)
     // profiling
     int prof = 0;                 // 0 off, N>=1: bracket every N-th launch of each family with events
     bool span_on = false;         // a sampled span of consecutive launches of ONE family is open (span_begin / span_end): its launches
@@ -272,6 +273,7 @@ bool recover_stream(s2sr_handle* h) {
 
 int ensure_scratch(s2sr_handle* h, int slot, size_t bytes) {
     h->tiles_slot = -1;                  // whoever asks for scratch is about to overwrite it; the pyramid calls set it again
+    h->warp_slot = -1;
     if (h->scratch_bytes[slot] >= bytes) return S2SR_OK;
     if (h->d_scratch[slot]) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1576,18 +1578,29 @@ static int enhance_impl(s2sr_handle* h, const uint8_t* img, int H, int W, int ti
             } else {
                 // LUTs, then every finishing band's kernels (in place: a band's rows are rewritten only after the apply pass, which
                 // runs R rows ahead, has read them), an event behind each; the copies follow band by band on the copy stream
+                const bool timing = getenv("S2SR_JOB_TIMING") != nullptr;     // diagnostic: stage times of the finish on stderr
+                auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+                double t_enq = now(), t_compute = 0, t_first = 0;
                 if ((rc = pp_band_lut_locked(h, st))) return rc;
                 for (int b = 0; b < nfin; ++b) {
                     const int y0 = b * fin_rows, y1 = y0 + fin_rows < OH ? y0 + fin_rows : OH;
                     if ((rc = pp_band_rows_locked(h, d_img_out, y0, y1, d_img_out, st))) return rc;
                     HIPCHK(h, hipEventRecord(h->group_done[nchunks + b], st));
                 }
+                if (timing) {
+                    HIPCHK(h, hipEventSynchronize(h->group_done[nchunks - 1]));
+                    t_compute = now();
+                }
                 for (int b = 0; b < nfin; ++b) {
                     const int y0 = b * fin_rows, y1 = y0 + fin_rows < OH ? y0 + fin_rows : OH;
                     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->group_done[nchunks + b], 0));
                     if ((rc = d2h_staged(h, out_u8 + (size_t)y0 * row_b, d_img_out + (size_t)y0 * row_b, (size_t)(y1 - y0) * row_b,
                                          false))) return rc;
+                    if (timing && b == 0) t_first = now();
                 }
+                if (timing)
+                    fprintf(stderr, "[s2sr job] finish: %d bands of %d rows; last chunk done %.2f ms after the finish was queued, first band on the host "
+                            "+%.2f ms, all bands +%.2f ms\n", nfin, fin_rows, t_compute - t_enq, t_first - t_compute, now() - t_compute);
             }
             HIPCHK(h, hipStreamSynchronize(h->copy_stream));
             HIPCHK(h, hipStreamSynchronize(st));
@@ -1879,12 +1892,13 @@ int s2sr_warp_bilinear_u8(s2sr_handle* h, const uint8_t* rgb, int32_t H, int32_t
     }
     HIPCHK(h, hipMemcpyAsync(out_rgba, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
+    h->warp_slot = 1; h->warp_h = OH; h->warp_w = OW;      // the raster also stays on the device for the base level of its pyramid
     return S2SR_OK;
 }
 
 int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W, const int32_t* col_lo, const int32_t* col_hi,
                        const int32_t* row_lo, const int32_t* row_hi, int32_t nx, int32_t ny, uint8_t* out) {
-    if (!h || !rgba || !col_lo || !col_hi || !row_lo || !row_hi || H <= 0 || W <= 0 || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
+    if (!h || !col_lo || !col_hi || !row_lo || !row_hi || H <= 0 || W <= 0 || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
     for (int i = 0; i < nx * 256; ++i)
         if (col_lo[i] < 0 || col_hi[i] >= W) return fail(h, S2SR_E_INVALID, "column footprint table leaves the raster");
     for (int i = 0; i < ny * 256; ++i)
@@ -1893,24 +1907,33 @@ int s2sr_tiles_base_u8(s2sr_handle* h, const uint8_t* rgba, int32_t H, int32_t W
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipStream_t st = h->stream;
     const size_t ib = (size_t)H * W * 4, ob = (size_t)nx * ny * 65536 * 4, cb = (size_t)nx * 256 * 4, rb = (size_t)ny * 256 * 4;
+    // rgba == NULL: the raster is the one the previous call on this handle -- s2sr_warp_bilinear_u8 -- produced, taken from its
+    // device copy (a 4096 x 4096 source: 67 MB that would cross PCIe twice between the two calls)
+    int in_slot = 0;
+    if (!rgba) {
+        if (h->warp_slot < 0 || h->warp_h != H || h->warp_w != W)
+            return fail(h, S2SR_E_INVALID, "rgba == NULL, but the previous call on this handle did not leave a warped raster of this size on the device");
+        in_slot = h->warp_slot;
+    }
+    const int out_slot = in_slot == 1 ? 0 : 1;
     int rc;
-    if ((rc = ensure_scratch(h, 0, ib))) return rc;
-    if ((rc = ensure_scratch(h, 1, ob))) return rc;
+    if (rgba && (rc = ensure_scratch(h, in_slot, ib))) return rc;
+    if ((rc = ensure_scratch(h, out_slot, ob))) return rc;
     if ((rc = ensure_scratch(h, 3, 2 * cb + 2 * rb))) return rc;
     int32_t* t = (int32_t*)h->d_scratch[3];
-    HIPCHK(h, hipMemcpyAsync(h->d_scratch[0], rgba, ib, hipMemcpyHostToDevice, st));
+    if (rgba) HIPCHK(h, hipMemcpyAsync(h->d_scratch[in_slot], rgba, ib, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(t, col_lo, cb, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(t + nx * 256, col_hi, cb, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(t + 2 * nx * 256, row_lo, rb, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(t + 2 * nx * 256 + ny * 256, row_hi, rb, hipMemcpyHostToDevice, st));
     {
         Scope sc(h, st, F_MISC, 0.0, (double)ib + (double)ob);
-        HIPCHK(h, launch_tiles_base((const uint8_t*)h->d_scratch[0], W, t, t + nx * 256, t + 2 * nx * 256, t + 2 * nx * 256 + ny * 256, nx,
-                                    ny, (uint8_t*)h->d_scratch[1], st));
+        HIPCHK(h, launch_tiles_base((const uint8_t*)h->d_scratch[in_slot], W, t, t + nx * 256, t + 2 * nx * 256, t + 2 * nx * 256 + ny * 256, nx,
+                                    ny, (uint8_t*)h->d_scratch[out_slot], st));
     }
-    if (out) HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[1], ob, hipMemcpyDeviceToHost, st));      // out == NULL: the level stays on the device
+    if (out) HIPCHK(h, hipMemcpyAsync(out, h->d_scratch[out_slot], ob, hipMemcpyDeviceToHost, st));      // out == NULL: the level stays on the device
     HIPCHK(h, hipStreamSynchronize(st));
-    h->tiles_slot = 1; h->tiles_nx = nx; h->tiles_ny = ny;
+    h->tiles_slot = out_slot; h->tiles_nx = nx; h->tiles_ny = ny;
     return S2SR_OK;
 }
 
@@ -2240,7 +2263,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
 // workgroup per CU, timed with an event pair on the handle's stream behind launches / 4 + 1 untimed ones (the clock settles under load)
 int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch, double* dma_bytes_per_launch,
                             float* ms_total) {
-    if (!h || mode < 0 || mode > 2 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
+    if (!h || mode < 0 || mode > 4 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int ncu = 256;
@@ -2265,7 +2288,7 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
     h->ceiling_filled = false;                            // scratch[2] is anybody's again
     if (flop_per_launch) *flop_per_launch = mfma_ceiling_flop_per_launch(ncu, stages);
-    if (dma_bytes_per_launch) *dma_bytes_per_launch = mode == 2 ? mfma_ceiling_dma_bytes_per_launch(ncu, stages) : 0.0;
+    if (dma_bytes_per_launch) *dma_bytes_per_launch = mfma_ceiling_dma_bytes_per_launch(mode, ncu, stages);
     return S2SR_OK;
 }
 

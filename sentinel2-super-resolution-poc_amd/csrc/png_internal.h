@@ -20,6 +20,8 @@ void build_block_code(const uint32_t* tok_freq, bool final_block, BlockCode* bc)
 uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n);
 uint32_t adler32_update(uint32_t adler, const uint8_t* p, size_t n);
 bool write_file(const char* path, const uint8_t* data, size_t n);     // makes missing parent directories
+struct Piece { const uint8_t* p; size_t n; };
+bool write_file_pieces(const char* path, const Piece* pieces, int count);   // the same from up to 8 pieces (one writev)
 
 }  // namespace png
 }  // namespace s2sr

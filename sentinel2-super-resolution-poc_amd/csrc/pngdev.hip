@@ -585,28 +585,38 @@ bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t defla
         }
     };
     static const Head H;
-    const uint8_t* head = H.b;
+    // The file goes out as three pieces (writev): the constant head + IDAT header, the deflate bytes straight from the staging
+    // buffer the DMA filled, and a small tail (the stream's last bytes with the end-of-block code merged in, Adler-32, the chunk's
+    // CRC, IEND).  r04 assembled every file in a per-thread buffer first: a 30-KB copy per tile in front of a table-walk CRC.
+    (void)buf;
     const size_t idat = 2 + (size_t)deflate_bytes + 4;
-    buf.resize(33 + 12 + idat + 12);
-    uint8_t* p = buf.data();
-    memcpy(p, head, 33);
-    p += 33;
-    p[0] = (uint8_t)(idat >> 24); p[1] = (uint8_t)(idat >> 16); p[2] = (uint8_t)(idat >> 8); p[3] = (uint8_t)idat;
-    memcpy(p + 4, "IDAT", 4);
-    p[8] = 0x78; p[9] = 0x01;
-    uint8_t* d = p + 10;
-    memcpy(d, words, deflate_bytes);
+    uint8_t head[43];
+    memcpy(head, H.b, 33);
+    head[33] = (uint8_t)(idat >> 24); head[34] = (uint8_t)(idat >> 16); head[35] = (uint8_t)(idat >> 8); head[36] = (uint8_t)idat;
+    memcpy(head + 37, "IDAT", 4);
+    head[41] = 0x78; head[42] = 0x01;
+    const size_t ntail = deflate_bytes < 16 ? deflate_bytes : 16;       // the end-of-block code lands in the last bytes (<= 4 of them)
+    const size_t nbody = deflate_bytes - ntail;
+    const uint8_t* src = (const uint8_t*)words;
+    uint8_t tail[16 + 20];
+    memcpy(tail, src + nbody, ntail);
     {   // the end-of-block code, LSB first at bit eob_at
         uint64_t v = (uint64_t)(eob & 0xFFFFFFu) << (eob_at & 7);
-        for (size_t k = eob_at >> 3; v; ++k, v >>= 8) d[k] |= (uint8_t)v;
+        for (size_t k = eob_at >> 3; v; ++k, v >>= 8) {
+            if (k < nbody || k >= deflate_bytes) return false;          // (cannot happen: the code ends inside the stream's last bytes)
+            tail[k - nbody] |= (uint8_t)v;
+        }
     }
-    uint8_t* tail = d + deflate_bytes;
-    tail[0] = (uint8_t)(adler >> 24); tail[1] = (uint8_t)(adler >> 16); tail[2] = (uint8_t)(adler >> 8); tail[3] = (uint8_t)adler;
-    const uint32_t crc = png::crc32_update(0, p + 4, 4 + idat);
-    tail[4] = (uint8_t)(crc >> 24); tail[5] = (uint8_t)(crc >> 16); tail[6] = (uint8_t)(crc >> 8); tail[7] = (uint8_t)crc;
+    uint8_t* t = tail + ntail;
+    t[0] = (uint8_t)(adler >> 24); t[1] = (uint8_t)(adler >> 16); t[2] = (uint8_t)(adler >> 8); t[3] = (uint8_t)adler;
+    uint32_t crc = png::crc32_update(0, head + 37, 6);
+    crc = png::crc32_update(crc, src, nbody);
+    crc = png::crc32_update(crc, tail, ntail + 4);
+    t[4] = (uint8_t)(crc >> 24); t[5] = (uint8_t)(crc >> 16); t[6] = (uint8_t)(crc >> 8); t[7] = (uint8_t)crc;
     static const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82};
-    memcpy(tail + 8, iend, 12);
-    return png::write_file(path, buf.data(), buf.size());
+    memcpy(t + 8, iend, 12);
+    const png::Piece pieces[3] = {{head, sizeof head}, {src, nbody}, {tail, ntail + 20}};
+    return png::write_file_pieces(path, pieces, 3);
 }
 
 bool png_parallel_for(int n, const std::function<void(int)>& body) { return parallel_for(n, body); }

@@ -10,7 +10,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <immintrin.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -40,9 +43,9 @@ const CrcTables& crc_tables() {
     return T;
 }
 }  // namespace
-uint32_t s2sr::png::crc32_update(uint32_t crc, const uint8_t* p, size_t n) {      // slice-by-8; crc is the running value (not inverted)
+namespace {
+uint32_t crc32_tables(uint32_t c /* running value, inverted */, const uint8_t* p, size_t n) {      // slice-by-8
     const CrcTables& T = crc_tables();
-    uint32_t c = ~crc;
     while (n >= 8) {
         uint32_t a, b;
         memcpy(&a, p, 4);
@@ -54,7 +57,76 @@ uint32_t s2sr::png::crc32_update(uint32_t crc, const uint8_t* p, size_t n) {    
         n -= 8;
     }
     while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
-    return ~c;
+    return c;
+}
+
+// CRC-32 by carry-less multiplication (Gopal et al., "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", the
+// bit-reflected form zlib's x86 builds use): four 128-bit lanes are folded over 64 bytes at a time with x^(512+-32) mod P, then into
+// one lane with x^(128+-32) mod P, then 128 -> 64 -> 32 bits with a Barrett reduction.  n >= 64 and a multiple of 16; ~10x the table
+// walk, which was 40 % of a tile file's host time in the pyramid's PNG stage (12.8k files of ~30 KB per pyramid).
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(uint32_t c /* running value, inverted */, const uint8_t* p, size_t n) {
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596, 0x0154442bd4);      // x^(4*128+32), x^(4*128-32) mod P (reflected)
+    const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009e, 0x01751997d0);      // x^(128+32), x^(128-32) mod P
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124);                   // x^64 mod P
+    const __m128i poly = _mm_set_epi64x(0x01f7011641, 0x01db710641);      // mu = floor(x^64 / P), P
+    __m128i x1 = _mm_loadu_si128((const __m128i*)(p + 0)), x2 = _mm_loadu_si128((const __m128i*)(p + 16));
+    __m128i x3 = _mm_loadu_si128((const __m128i*)(p + 32)), x4 = _mm_loadu_si128((const __m128i*)(p + 48));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)c));
+    p += 64;
+    n -= 64;
+    while (n >= 64) {
+        const __m128i l1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), l2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+        const __m128i l3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), l4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11);
+        x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11);
+        x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, l1), _mm_loadu_si128((const __m128i*)(p + 0)));
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, l2), _mm_loadu_si128((const __m128i*)(p + 16)));
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, l3), _mm_loadu_si128((const __m128i*)(p + 32)));
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, l4), _mm_loadu_si128((const __m128i*)(p + 48)));
+        p += 64;
+        n -= 64;
+    }
+    auto fold1 = [&](__m128i acc, __m128i next) __attribute__((target("pclmul,sse4.1"))) {
+        const __m128i lo = _mm_clmulepi64_si128(acc, k3k4, 0x00);
+        return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(acc, k3k4, 0x11), next), lo);
+    };
+    x1 = fold1(x1, x2);
+    x1 = fold1(x1, x3);
+    x1 = fold1(x1, x4);
+    while (n >= 16) {
+        x1 = fold1(x1, _mm_loadu_si128((const __m128i*)p));
+        p += 16;
+        n -= 16;
+    }
+    // 128 -> 64 bits
+    const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+    t = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), k5, 0x00), t);
+    // Barrett reduction to 32 bits
+    t = _mm_and_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, mask32), poly, 0x10), mask32);
+    x1 = _mm_xor_si128(x1, _mm_clmulepi64_si128(t, poly, 0x00));
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+
+bool have_clmul() {
+    static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !getenv("S2SR_CRC_TABLES");
+    return ok;
+}
+}  // namespace
+
+uint32_t s2sr::png::crc32_update(uint32_t crc, const uint8_t* p, size_t n) {      // crc is the running value (not inverted)
+    uint32_t c = ~crc;
+    if (n >= 64 && have_clmul()) {
+        const size_t body = n & ~(size_t)15;
+        c = crc32_clmul(c, p, body);
+        p += body;
+        n -= body;
+    }
+    return ~crc32_tables(c, p, n);
 }
 uint32_t s2sr::png::adler32_update(uint32_t adler, const uint8_t* p, size_t n) {
     uint32_t a = adler & 0xFFFF;
@@ -532,28 +604,47 @@ extern "C" int s2sr_png_idat_band(const uint8_t* px, int32_t width, int32_t rows
     return S2SR_OK;
 }
 
-bool s2sr::png::write_file(const char* path, const uint8_t* data, size_t n) {
+namespace {
+int open_for_write(const char* path) {
     int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd < 0 && errno == ENOENT) {                 // z/x/ does not exist yet: make the missing directories, once
         std::string p(path);
         for (size_t k = 1; k < p.size(); ++k)
             if (p[k] == '/') {
                 p[k] = 0;
-                if (mkdir(p.c_str(), 0755) != 0 && errno != EEXIST) return false;
+                if (mkdir(p.c_str(), 0755) != 0 && errno != EEXIST) return -1;
                 p[k] = '/';
             }
         fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     }
+    return fd;
+}
+}  // namespace
+
+bool s2sr::png::write_file(const char* path, const uint8_t* data, size_t n) {
+    const Piece one = {data, n};
+    return write_file_pieces(path, &one, 1);
+}
+
+bool s2sr::png::write_file_pieces(const char* path, const Piece* pieces, int count) {
+    if (count < 1 || count > 8) return false;
+    const int fd = open_for_write(path);
     if (fd < 0) return false;
-    size_t at = 0;
+    struct iovec iov[8];
+    int n = 0;
+    for (int i = 0; i < count; ++i)
+        if (pieces[i].n) { iov[n].iov_base = (void*)pieces[i].p; iov[n].iov_len = pieces[i].n; ++n; }
+    int at = 0;
     while (at < n) {
-        const ssize_t w = write(fd, data + at, n - at);
+        const ssize_t w = writev(fd, iov + at, n - at);
         if (w < 0) {
             if (errno == EINTR) continue;
             close(fd);
             return false;
         }
-        at += (size_t)w;
+        size_t left = (size_t)w;                     // a short write: step over what went out
+        while (at < n && left >= iov[at].iov_len) left -= iov[at++].iov_len;
+        if (at < n && left) { iov[at].iov_base = (char*)iov[at].iov_base + left; iov[at].iov_len -= left; }
     }
     return close(fd) == 0;
 }

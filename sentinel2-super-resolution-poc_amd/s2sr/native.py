@@ -604,18 +604,26 @@ class Engine:
     def warp_bilinear_u8(self, rgb: np.ndarray, grid: np.ndarray, step: int, out_h: int, out_w: int) -> np.ndarray:
         rgb = np.ascontiguousarray(rgb, np.uint8)
         grid = np.ascontiguousarray(grid, np.float32)
-        out = np.empty((out_h, out_w, 4), np.uint8)
+        out = pinned_pool.empty((out_h, out_w, 4), np.uint8)        # (page-locked when large: the raster comes back with one DMA)
         self._check(self._lib.s2sr_warp_bilinear_u8(self._h, _ptr(rgb), rgb.shape[0], rgb.shape[1], _ptr(grid), grid.shape[0],
                                                     grid.shape[1], step, out_h, out_w, _ptr(out)), "s2sr_warp_bilinear_u8")
         return out
 
-    def tiles_base_u8(self, rgba: np.ndarray, col_lo, col_hi, row_lo, row_hi, fetch: bool = True) -> Optional[np.ndarray]:
-        """fetch=False: the level is computed and left on the device (for tiles_write_png / the next overview); returns None."""
-        rgba = np.ascontiguousarray(rgba, np.uint8)
+    def tiles_base_u8(self, rgba, col_lo, col_hi, row_lo, row_hi, fetch: bool = True, on_device: bool = False) -> Optional[np.ndarray]:
+        """fetch=False: the level is computed and left on the device (for tiles_write_png / the next overview); returns None.
+        on_device: the raster is the one the previous call on this engine -- warp_bilinear_u8 -- produced and nothing else ran on the
+        engine since: its device copy is used instead of an upload; `rgba` is then only read for its shape (array or (H, W))."""
+        if on_device:
+            H, W = rgba.shape[:2] if hasattr(rgba, "shape") else rgba
+            src = None
+        else:
+            rgba = np.ascontiguousarray(rgba, np.uint8)
+            H, W = rgba.shape[:2]
+            src = _ptr(rgba)
         t = [np.ascontiguousarray(a, np.int32) for a in (col_lo, col_hi, row_lo, row_hi)]
         nx, ny = t[0].size // 256, t[2].size // 256
         out = np.empty((ny, nx, 256, 256, 4), np.uint8) if fetch else None
-        self._check(self._lib.s2sr_tiles_base_u8(self._h, _ptr(rgba), rgba.shape[0], rgba.shape[1], _ptr(t[0]), _ptr(t[1]), _ptr(t[2]),
+        self._check(self._lib.s2sr_tiles_base_u8(self._h, src, H, W, _ptr(t[0]), _ptr(t[1]), _ptr(t[2]),
                                                  _ptr(t[3]), nx, ny, _ptr(out) if fetch else None), "s2sr_tiles_base_u8")
         return out
 

@@ -5,6 +5,9 @@ writer below (strips / tiles, chunky / planar, Deflate + predictor, big endian, 
 import struct
 import zlib
 
+import os
+from pathlib import Path
+
 import numpy as np
 import pytest
 from PIL import Image
@@ -313,6 +316,17 @@ def test_native_png_encoder_decodes_to_the_input():
     roundtrip(vals[:vals.size // 12 * 12].reshape(-1, 4, 3), "fibonacci")
     big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
     roundtrip(big[10:200, 20:300], "view")
+    # the chunk CRCs come from the carry-less-multiply CRC-32 where the CPU has it (pngenc.hip crc32_clmul); S2SR_CRC_TABLES=1
+    # selects the table walk: a fresh process with it must write the same files
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from s2sr import native; "
+            "rng = np.random.default_rng(3); "
+            "sys.stdout.buffer.write(b''.join(native.png_encode(rng.integers(0, 256, s, dtype=np.uint8)) for s in ((3, 5, 3), (40, 41, 4), (256, 256, 4))))"
+            % str(Path(__file__).resolve().parent.parent / "sentinel2-super-resolution-poc_amd"))
+    outs = [subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, check=True).stdout
+            for env in ({}, {"S2SR_CRC_TABLES": "1"})]
+    assert len(outs[0]) > 1000 and outs[0] == outs[1]
     # a compressible tile must actually compress, about as well as zlib with the same settings
     yy, xx = np.mgrid[0:256, 0:256]
     tile = np.empty((256, 256, 4), np.uint8)
