@@ -298,7 +298,7 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
     out = {"note": "one workgroup per CU, 8 waves, random fp16 operands in (-1, 1); stages of 288 MFMAs / 216 ds_read_b128 / 48 KiB LDS-DMA per "
                    "workgroup as in conv_trunk_f16 conv1-4 (28 stages per workgroup = the MFMA work of one launch of 16 images); no epilogue, no stores",
            "stages_per_launch": 448}
-    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (3, "lds_dma_fed_half_bytes"), (4, "lds_dma_fed_from_cache")):
+    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (5, "lds_dma_fed_kernel_mix"), (3, "lds_dma_fed_half_bytes"), (4, "lds_dma_fed_from_cache")):
         probe = eng.mfma_ceiling(mode, 448, 8)                         # settles the clock and sizes the timed run
         launches = int(max(16, min(4000, (0.8e6 if mode <= 2 else 0.5e6) / max(probe["us_per_launch"], 1.0))))
         sampler = ClockSampler(device_index)
@@ -309,6 +309,10 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
                "seconds": round(r["ms"] * 1e-3, 3), "launches": launches}
         if mode >= 2:
             leg["lds_dma_GB_per_s"] = round(r["dma_GB_per_s"], 1)
+        if mode == 5:
+            leg["what"] = ("the kernel's own traffic mix: 36 of the 48 KiB per stage streamed from HBM (slab planes), 12 KiB from a cached source (the weights "
+                           "every workgroup re-fetches), 8 KiB stored per stage (the launch's output): per 16-image launch 264 MB read + 59 MB written, against "
+                           "243 + 67 MB in the counters of conv1-4; lds_dma_GB_per_s counts all 48 KiB")
         if mode == 3:
             leg["what"] = "lds_dma_fed with 24 KiB of LDS-DMA per 288 MFMAs: what a schedule that moved half the bytes per FLOP would be fed at"
         if mode == 4:
@@ -812,8 +816,11 @@ def main():
             sec["mfma_ceiling"] = mfma_ceiling_leg(eng, local)
             if a.precision != "fp8" and rank == 0:
                 fed = sec["mfma_ceiling"]["lds_dma_fed"]["TFLOP_per_s"]
+                mix = sec["mfma_ceiling"]["lds_dma_fed_kernel_mix"]["TFLOP_per_s"]
                 line["roofline"]["frac_of_fed_ceiling"] = round(line["roofline"]["achieved"] / fed, 4)
                 line["roofline"]["fed_ceiling_TFLOP_per_s"] = fed
+                line["roofline"]["frac_of_fed_ceiling_kernel_mix"] = round(line["roofline"]["achieved"] / mix, 4)
+                line["roofline"]["fed_ceiling_kernel_mix_TFLOP_per_s"] = mix
                 line["roofline"]["bare_loop_TFLOP_per_s"] = sec["mfma_ceiling"]["bare"]["TFLOP_per_s"]
         except Exception as e:      # noqa: BLE001
             sec["mfma_ceiling"] = {"error": f"{type(e).__name__}: {e}"}

@@ -11,6 +11,9 @@
 //                     counted vmcnt + one barrier per stage like the kernel)
 //   mode 3            as 2 with half the fill (24 KiB per 288 MFMAs): what a schedule that moved half the bytes per FLOP would get
 //   mode 4            as 2 from an 8-MB source that stays in L2 / MALL: the LDS-DMA issue and fill without the HBM side
+//   mode 5  the kernel's own mix: 36 KiB of the 48 streamed from HBM (the slab plane), 12 KiB from the cached source (the weights:
+//           every workgroup fetches the same ones), and 8 KiB stored per stage (the launch's output: 32 channels of fp16 per pixel)
+//           -- per launch of 16 images 264 MB read + 59 MB written against the 243 + 67 MB the counters see for conv1-4
 // Random fp16 operands in (-1, 1) (toggle rates, and with them power, depend on the data).  Two waves per SIMD so that LDS latency
 // hides without hand scheduling: these are ceilings, the occupancy is free to choose.  Diagnostic entry; nothing of the product
 // calls it.
@@ -26,6 +29,7 @@ namespace {
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int STAGE = 48 * 1024;     // LDS bytes of one pipeline stage (the kernel's 46 KiB rounded up to 6 KiB per wave)
 constexpr int RING = 3;              // stages in the ring (conv1-4 form: 3 x 46 KiB)
@@ -38,8 +42,12 @@ __device__ __forceinline__ void mfma(f32x16& acc, const f16x8& a, const f16x8& b
     asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void glds16(const char* base, uint32_t voff, uint32_t lds_addr) {
+    // base and LDS address are wave-uniform by construction; say so (the mix mode derives them from the wave index)
+    const uint64_t v = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    base = (const char*)(((uint64_t)hi << 32) | lo);
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ f16x8 lds16(const char* smem, uint32_t off) { return *(const f16x8*)(smem + off); }
 
@@ -52,8 +60,9 @@ __global__ void fill_random_f16(uint32_t* dst, size_t n_words) {
     }
 }
 
-template <int MODE, int PW>        // MODE 0 bare, 1 + LDS reads, 2 + LDS-DMA of PW KiB per wave and stage
-__global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restrict__ src, uint32_t nchunks, float* __restrict__ sink, int stages) {
+template <int MODE, int PW, bool MIX = false>        // MODE 0 bare, 1 + LDS reads, 2 + LDS-DMA of PW KiB per wave and stage; MIX: mode 5
+__global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restrict__ src, uint32_t nchunks, float* __restrict__ sink, int stages,
+                                                           char* __restrict__ store, uint32_t store_kib) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // the ring starts full of operand data (all modes take their first fragments from it)
@@ -71,8 +80,14 @@ __global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restric
     f16x8 a0 = lds16(smem, lane_off), a1 = lds16(smem, 1024 + lane_off), a2 = lds16(smem, 2048 + lane_off), b = lds16(smem, 3072 + lane_off);
 
     // LDS-DMA of stage s: this wave's PW KiB of chunk (s * gridDim.x + blockIdx.x) % nchunks into ring slot s % RING
+    constexpr uint32_t kCached = 160;      // chunks at the front of the source that MIX's "weight" pieces keep re-reading (7.5 MB)
     auto dma = [&](int s, int p) {
-        const uint32_t chunk = ((uint32_t)s * gridDim.x + blockIdx.x) % nchunks;
+        uint32_t chunk = ((uint32_t)s * gridDim.x + blockIdx.x) % nchunks;
+        if (MIX) {
+            // waves 0-3: pieces 0-4 streamed, piece 5 cached; waves 4-7: pieces 0-3 streamed, 4-5 cached -> 36 KiB / 12 KiB per stage
+            const bool cached = p >= (wave < 4 ? 5 : 4);
+            chunk = cached ? chunk % kCached : kCached + chunk % (nchunks - kCached);
+        }
         const uint32_t piece = (uint32_t)(wave * PW_FULL + p) * 1024;
         glds16(src + (size_t)chunk * STAGE, piece + lane_off, (uint32_t)(s % RING) * STAGE + piece);
     };
@@ -87,7 +102,14 @@ __global__ void __launch_bounds__(512) mfma_ceiling_kernel(const char* __restric
         if (MODE == 2) {
             // my pieces of stage s have landed (all but the PW of stage s + 1 are done), my reads of the slot about to be refilled
             // have returned; past the barrier both hold for every wave
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (RING - 2)) : "memory");
+            // (MIX: + the one store of the stage before, issued in front of that stage's pieces)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (RING - 2) + (MIX ? 1 : 0)) : "memory");
+            if (MIX) {      // the stage's share of the launch's output: 1 KiB per wave, streaming through a 64-MB region
+                const uint32_t kib = (((uint32_t)s * gridDim.x + blockIdx.x) * WAVES + (uint32_t)wave) % store_kib;
+                float* q = (float*)(store + (size_t)kib * 1024 + lane_off);
+                const f32x4 v4 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};      // (a fixed accumulator: a run-time index would put them all in scratch)
+                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(q), "v"(v4) : "memory");
+            }
         } else if (MODE == 1) {
             asm volatile("" ::: "memory");
         }
@@ -125,29 +147,31 @@ namespace s2sr {
 
 // src: >= nchunks * 48 KiB of operand data (filled here on first use when `fill`), sink: gridDim * 512 floats.  Returns the
 // launch error; FLOP of one launch = grid * stages * 8 waves * 36 MFMAs * 32768.
-hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, hipStream_t st) {
-    if (mode < 0 || mode > 4 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
+hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, char* d_store,
+                               size_t store_bytes, hipStream_t st) {
+    if (mode == 5 && (!d_store || store_bytes < (1u << 20))) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 5 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
     if (fill) hipLaunchKernelGGL(fill_random_f16, dim3(2048), dim3(256), 0, st, (uint32_t*)d_src, src_bytes / 4);
     uint32_t nchunks = (uint32_t)(src_bytes / STAGE);
     const size_t lds = (size_t)RING * STAGE;
-    typedef void (*K)(const char*, uint32_t, float*, int);
-    static const K kern[5] = {mfma_ceiling_kernel<0, PW_FULL>, mfma_ceiling_kernel<1, PW_FULL>, mfma_ceiling_kernel<2, PW_FULL>,
-                              mfma_ceiling_kernel<2, PW_FULL / 2>, mfma_ceiling_kernel<2, PW_FULL>};
+    typedef void (*K)(const char*, uint32_t, float*, int, char*, uint32_t);
+    static const K kern[6] = {mfma_ceiling_kernel<0, PW_FULL>, mfma_ceiling_kernel<1, PW_FULL>, mfma_ceiling_kernel<2, PW_FULL>,
+                              mfma_ceiling_kernel<2, PW_FULL / 2>, mfma_ceiling_kernel<2, PW_FULL>, mfma_ceiling_kernel<2, PW_FULL, true>};
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        for (int m = 0; m < 5 && attr_err == hipSuccess; ++m)
+        for (int m = 0; m < 6 && attr_err == hipSuccess; ++m)
             attr_err = hipFuncSetAttribute((const void*)kern[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (attr_err != hipSuccess) return attr_err;
     if (mode == 4) nchunks = nchunks < 160 ? nchunks : 160;       // 7.5 MB of source: resident in L2 / MALL
-    hipLaunchKernelGGL(kern[mode], dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages);
+    hipLaunchKernelGGL(kern[mode], dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages, d_store, (uint32_t)(store_bytes >> 10));
     return hipGetLastError();
 }
 
 double mfma_ceiling_flop_per_launch(int grid, int stages) { return (double)grid * stages * WAVES * (3.0 * STEPS) * 32768.0; }
 double mfma_ceiling_dma_bytes_per_launch(int mode, int grid, int stages) {
-    return mode < 2 ? 0.0 : (double)grid * stages * (mode == 3 ? STAGE / 2 : STAGE);
+    return mode < 2 ? 0.0 : (double)grid * stages * (mode == 3 ? STAGE / 2 : STAGE);      // (mode 5: 36 of the 48 KiB come from HBM)
 }
 
 }  // namespace s2sr

@@ -2263,7 +2263,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
 // workgroup per CU, timed with an event pair on the handle's stream behind launches / 4 + 1 untimed ones (the clock settles under load)
 int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch, double* dma_bytes_per_launch,
                             float* ms_total) {
-    if (!h || mode < 0 || mode > 4 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
+    if (!h || mode < 0 || mode > 5 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int ncu = 256;
@@ -2272,16 +2272,18 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     const bool fresh = h->scratch_bytes[2] < src_bytes || !h->ceiling_filled;
     int rc = ensure_scratch(h, 2, src_bytes);
     if (rc) return rc;
-    if ((rc = ensure_scratch(h, 3, (size_t)ncu * 512 * 4))) return rc;
+    const size_t sink_bytes = (size_t)ncu * 512 * 4, store_bytes = (size_t)64 << 20;      // mode 5 streams its stores through 64 MB
+    if ((rc = ensure_scratch(h, 3, sink_bytes + store_bytes))) return rc;
+    char* d_store = (char*)h->d_scratch[3] + sink_bytes;
     hipStream_t st = h->stream;
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
-    HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, fresh, (float*)h->d_scratch[3], ncu, stages, st));
+    HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, fresh, (float*)h->d_scratch[3], ncu, stages, d_store, store_bytes, st));
     h->ceiling_filled = true;
     for (int i = 0; i < launches / 4; ++i)
-        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, st));
+        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, d_store, store_bytes, st));
     HIPCHK(h, hipEventRecord(e0, st));
     for (int i = 0; i < launches; ++i)
-        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, st));
+        HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, d_store, store_bytes, st));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));

@@ -260,24 +260,27 @@ __global__ void __launch_bounds__(256) clahe_hist_kernel(const uint8_t* __restri
 // An AOI's mosaic is complete band by band (engine.hip enhance_impl, s2sr/dist.py); its histograms accumulate band by band under
 // the compute of the windows still to come.  A source row feeds the padded rows that map to it (itself, and its reflections in
 // the BORDER_REFLECT_101 padding), so the workgroups walk their CLAHE tile's padded rows and keep those whose source row is in
-// the band: integer counts, the same totals in any split.  grid.x = tile columns * split, grid.y = tile rows ty_lo..ty_hi.
-__global__ void __launch_bounds__(256) clahe_hist_rows_kernel(const uint8_t* __restrict__ img, ClaheGeom gm, int ty_lo,
+// the band: integer counts, the same totals in any split.  grid.x = tile columns, grid.y = (tile rows ty_lo..ty_hi) x chunks of
+// gm.split padded rows: a workgroup takes ~32k pixels, so one 1024-row band of a 16384-wide mosaic is 512 workgroups (the first form
+// cut a tile into 8 parts whatever the band: 32 busy workgroups per band, 1.1 ms each, 17 ms over the 16 bands of a 4096 x 4096 AOI).
+// One histogram per wave (waves take different rows; their lanes still meet on equal L values of neighbouring pixels).
+__global__ void __launch_bounds__(256) clahe_hist_rows_kernel(const uint8_t* __restrict__ img, ClaheGeom gm, int ty_lo, int chunks_per_tile,
                                                               const PPTables* __restrict__ t, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t sh[256];
+    __shared__ uint32_t sh[4][256];
     __shared__ PPTables s_t;
-    const int part = blockIdx.x % gm.split, tx = blockIdx.x / gm.split, ty = ty_lo + blockIdx.y;
-    const int rows_per = (gm.th + gm.split - 1) / gm.split;
-    const int r0 = part * rows_per, r1 = min(gm.th, r0 + rows_per);
-    // any row of this workgroup in the band?  (wave-uniform scan over at most th rows; most workgroups of a band leave here)
+    const int tx = blockIdx.x, ty = ty_lo + (int)blockIdx.y / chunks_per_tile, part = (int)blockIdx.y % chunks_per_tile;
+    const int r0 = part * gm.split, r1 = min(gm.th, r0 + gm.split);
+    // any row of this workgroup in the band?  (wave-uniform scan over at most gm.split rows; most workgroups of a band leave here)
     bool any = false;
     for (int r = r0; r < r1 && !any; ++r) {
         const int sy = reflect101(ty * gm.th + r, gm.H);
         any = sy >= gm.y0 && sy < gm.y1;
     }
     if (!any) return;
-    sh[threadIdx.x] = 0;
-    t = stage_tables(t, &s_t);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) sh[w][threadIdx.x] = 0;
+    t = stage_tables(t, &s_t);
     for (int r = r0 + wave; r < r1; r += 4) {
         const int sy = reflect101(ty * gm.th + r, gm.H);
         if (sy < gm.y0 || sy >= gm.y1) continue;
@@ -287,11 +290,11 @@ __global__ void __launch_bounds__(256) clahe_hist_rows_kernel(const uint8_t* __r
             const uint8_t* p = row + (size_t)sx * 3;
             int L, A, B;
             rgb2lab(t, p[gm.bgr ? 2 : 0], p[1], p[gm.bgr ? 0 : 2], L, A, B);
-            atomicAdd(&sh[L], 1u);
+            atomicAdd(&sh[wave][L], 1u);
         }
     }
     __syncthreads();
-    const uint32_t v = sh[threadIdx.x];
+    const uint32_t v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
     if (v) atomicAdd(&hist[(size_t)(ty * gm.grid + tx) * 256 + threadIdx.x], v);
 }
 
@@ -815,12 +818,13 @@ hipError_t launch_pp_band_hist(const uint8_t* d_img, int H, int W, const s2sr_pp
     int ty_lo = y0 / g.th, ty_hi = (y1 - 1) / g.th;
     if (pad > 0 && (pad >= H || y1 > H - 1 - pad)) ty_hi = g.grid - 1;
     if (pad >= H) ty_lo = 0;
-    // rows a tile row contributes to this band are at most min(th, y1 - y0): keep ~8 rows per wave and >= 512 workgroups when there are
-    const int rows = g.th < (y1 - y0) ? g.th : (y1 - y0);
-    g.split = rows >= 256 ? 8 : (rows >= 64 ? 4 : 1);
-    if (g.split > g.th) g.split = 1;
-    hipLaunchKernelGGL(clahe_hist_rows_kernel, dim3((unsigned)(g.grid * g.split), (unsigned)(ty_hi - ty_lo + 1)), dim3(256), 0, st, d_img, g,
-                       ty_lo, t, band_work(d_work, prm).hist);
+    // chunks of g.split padded rows, ~32k pixels per workgroup (each stages 14 KiB of tables), at least one row per wave
+    g.split = 32768 / g.tw;
+    if (g.split < 4) g.split = 4;
+    if (g.split > g.th) g.split = g.th;
+    const int chunks = (g.th + g.split - 1) / g.split;
+    hipLaunchKernelGGL(clahe_hist_rows_kernel, dim3((unsigned)g.grid, (unsigned)((ty_hi - ty_lo + 1) * chunks)), dim3(256), 0, st, d_img, g,
+                       ty_lo, chunks, t, band_work(d_work, prm).hist);
     return hipGetLastError();
 }
 

@@ -45,6 +45,19 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int, int]:
     return first, count, per
 
 
+def sharding_pays(H: int, W: int, tile: int = 256, world: int = 8, min_windows_per_rank: int = 16) -> bool:
+    """Should ONE image be sharded over `world` GPUs (enhance_distributed), or should the GPUs take whole jobs each (replicas:
+    app.sr_routes.GpuAdmission hands every job a device)?  Strong scaling is for large AOIs only: a rank's block has to fill its
+    GPU.  The unit is one launch image of window mosaics -- 4 x 4 windows of 276 x 276 = 1225 patches of 32 x 32 = 4.8 rounds of the
+    256 persistent workgroups; below that a rank runs under-filled rounds (the reference's real clip, 1024 x 1024 = 16 windows, would
+    put 2 windows = 162 patches on each of 8 GPUs: one round where 256 CUs get 162 patches, ~4x at best, against 8x for eight
+    such jobs side by side).  True: shard; False: route the job to one GPU."""
+    if H * W <= tile * tile * 4:
+        return False                    # the whole-image branch is a single unit (cnn_super_resolution.py:226)
+    windows = (-(-H // tile)) * (-(-W // tile))
+    return world > 1 and windows >= min_windows_per_rank * world
+
+
 def broadcast_weights(state_dict, num_block: int, device: torch.device, src: int = 0) -> torch.Tensor:
     """Rank `src` flattens its state-dict; everyone receives the fp32 blob (ONE broadcast, 66.8 MB for
     the 23-block net) as a tensor on `device`.  It stays fp32 on the wire: the high-precision mode splits

@@ -207,6 +207,15 @@ def test_rank_count_invariance(world):
     assert np.array_equal(res[-1], e)
 
 
+def test_small_aois_are_routed_as_replicas():
+    """Strong scaling is for AOIs whose windows fill every rank's GPU: the reference's real clip (1024 x 1024,
+    16 windows) and anything on the whole-image branch stay on one GPU; the 4096 x 4096 AOI of configs[2] is sharded at 8 ranks."""
+    from s2sr.dist import sharding_pays
+    assert not sharding_pays(1024, 1024, 256, 8) and not sharding_pays(512, 512, 256, 8) and not sharding_pays(2048, 2048, 256, 8)
+    assert sharding_pays(4096, 4096, 256, 8) and sharding_pays(2048, 2048, 256, 4) and sharding_pays(1024, 1024, 256, 1) is False
+    assert sharding_pays(3000, 3000, 256, 8)            # 144 windows: 18 per rank
+
+
 def test_shard_range_covers_everything():
     from s2sr.dist import shard_range
     for total in (0, 1, 5, 16, 17, 100):
