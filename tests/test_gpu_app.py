@@ -386,6 +386,8 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     ao = d["aoi_strong_scaling"]
     assert ao["n_gpus"] == 2 and ao["scaling"] == "strong" and ao["value"] > 0 and ao["rccl_ranks_seen"] == 2
     assert "blocks of 8 per rank" in ao["workload"]
+    # ... and in the flavour the reference requests by default (enhance_crops=True: band histograms, LUTs, finish in row bands)
+    assert ao["enhance_crops"]["value"] > 0 and ao["enhance_crops"]["seconds"] > 0
 
 
 def test_enhance_job_equals_the_separate_steps(monkeypatch, tmp_path):
