@@ -241,6 +241,10 @@ int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, i
 #define S2SR_PNG_HOST_ENCODER     2
 #define S2SR_PNG_ROW_THREADS      4   /* the first form of the two kernels (one thread walks one row): same bytes, kept as the check */
 int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written);
+/* the same for the XYZ layout gdal2tiles writes (tiling.py:138-186): tile (row j, column i) of the level goes to
+ * <dir>/<zoom>/<x0 + i>/<y_rows[j]>.png -- the caller hands over ny row numbers instead of nx * ny path strings */
+int  s2sr_tiles_write_png_xyz(s2sr_handle* h, int32_t nx, int32_t ny, const char* dir, int32_t zoom, int32_t x0, const int32_t* y_rows,
+                              int32_t flags, int32_t* written);
 
 /* measurement: HIP-event timing per kernel family on the launch stream.  on = 0: off;
  * on = N >= 1: every N-th launch of each family is bracketed by a hipEvent pair (N > 1 keeps

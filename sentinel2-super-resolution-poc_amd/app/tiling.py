@@ -173,8 +173,8 @@ def _cut_pyramid(rgba: np.ndarray, place: geo.Placement, output_dir: Path, min_z
                 ox, oy = tiles.overview_offsets(lv, prev_lv)
                 eng.tiles_overview_u8((prev_lv.ny, prev_lv.nx), ox, oy, lv.nx, lv.ny, on_device=True, fetch=False)
             t1 = time.perf_counter()
-            paths = [f"{output_dir}/{lv.zoom}/{lv.tminx + i}/{geo.xyz_row(lv.tmaxy - j, lv.zoom)}.png" for j in range(lv.ny) for i in range(lv.nx)]
-            eng.tiles_write_png(lv.nx, lv.ny, paths)              # tiles outside the raster (alpha 0 everywhere) get no file
+            # <output_dir>/<z>/<x>/<y>.png; tiles outside the raster (alpha 0 everywhere) get no file
+            eng.tiles_write_png_xyz(lv.nx, lv.ny, output_dir, lv.zoom, lv.tminx, [geo.xyz_row(lv.tmaxy - j, lv.zoom) for j in range(lv.ny)])
             prev_lv = lv
             t_dev += t1 - t0
             t_png += time.perf_counter() - t1

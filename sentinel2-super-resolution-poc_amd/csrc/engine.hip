@@ -175,6 +175,8 @@ struct s2sr_handle {
     uint64_t stitch_clock = 0;
     hipEvent_t host_copy_ev = nullptr;          // s2sr_copy_to_host: orders the copy stream behind the caller's stream
     bool ceiling_filled = false;                // s2sr_debug_mfma_ceiling: scratch[2] holds its operand data
+    void* host_arena = nullptr;                 // page-locked host block of the tile-PNG stage (stats back, plan up): grown on demand, kept
+    size_t host_arena_bytes = 0;
     // the banded post-process in progress on this handle (s2sr_pp_band_*_dev, enhance_impl): geometry, channel order, how far the
     // CLAHE'd rows and the finished rows reach
     struct PPBand {
@@ -982,6 +984,7 @@ void s2sr_destroy(s2sr_handle* h) {
     }
     for (auto& m : h->stitch_sets)
         if (m.d) dev_free(m.d);
+    if (h->host_arena) host_free(h->host_arena);
     if (h->host_copy_ev) hipEventDestroy(h->host_copy_ev);
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1970,9 +1973,36 @@ int s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, in
 // The PNG files of the tile level the previous base / overview call left on the device: token statistics on the device, Huffman
 // codes on the host, bit emission on the device, chunk framing + CRC + file writes on host threads (pngdev.hip).  Only the
 // compressed streams cross PCIe.
+static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written);
+
 int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written) {
     if (!h || !paths || nx <= 0 || ny <= 0) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    return tiles_write_png_locked(h, nx, ny, paths, flags, written);
+}
+
+// The same with the XYZ layout spelled out instead of nx * ny path strings: tile (j, i) of the level goes to
+// <dir>/<zoom>/<x0 + i>/<y_rows[j]>.png (gdal2tiles --xyz, reference tiling.py:138-186).  A z18 level is 9801 paths: built here they
+// cost a millisecond, as Python strings plus a ctypes array 5-7 ms per level.
+int s2sr_tiles_write_png_xyz(s2sr_handle* h, int32_t nx, int32_t ny, const char* dir, int32_t zoom, int32_t x0, const int32_t* y_rows,
+                             int32_t flags, int32_t* written) {
+    if (!h || !dir || !y_rows || nx <= 0 || ny <= 0 || zoom < 0) return S2SR_E_INVALID;
+    const size_t dl = strlen(dir);
+    if (dl == 0 || dl > 3800) return S2SR_E_INVALID;
+    const size_t slot = dl + 48;                                  // "/zz/xxxxxxxxxx/yyyyyyyyyy.png" is at most 30 characters
+    std::vector<char> text((size_t)nx * ny * slot);
+    std::vector<const char*> paths((size_t)nx * ny);
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            char* p = text.data() + ((size_t)j * nx + i) * slot;
+            snprintf(p, slot, "%s/%d/%d/%d.png", dir, zoom, x0 + i, y_rows[j]);
+            paths[(size_t)j * nx + i] = p;
+        }
+    std::lock_guard<std::mutex> lk(h->mu);
+    return tiles_write_png_locked(h, nx, ny, paths.data(), flags, written);
+}
+
+static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->tiles_slot < 0 || h->tiles_nx != nx || h->tiles_ny != ny)
         return fail(h, S2SR_E_INVALID, "the previous call on this handle did not leave a tile level of this size on the device");
@@ -1993,23 +2023,33 @@ int s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* con
         Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0);      // algorithmic: every tile byte once
         HIPCHK(h, launch_png_tile_stats(d_tiles, n, d_hist, d_adl, d_flag, (flags & S2SR_PNG_ROW_THREADS) != 0, st));
     }
-    std::vector<uint32_t> stats((hist_b + adl_b + flag_b) / 4);
-    HIPCHK(h, hipMemcpyAsync(stats.data(), d_hist, hist_b + adl_b + flag_b, hipMemcpyDeviceToHost, st));
+    // the statistics come back into, and the plan goes up from, ONE page-locked block kept on the handle (a z18 level: 40 MB down,
+    // 27 MB up; as fresh pageable vectors each crossed PCIe through the runtime's staging and was page-faulted in first)
+    const size_t stats_b = (hist_b + adl_b + flag_b + 255) & ~(size_t)255, plan_b = png_plan_bytes(n);
+    if (h->host_arena_bytes < stats_b + plan_b) {
+        if (h->host_arena) HIPCHK(h, host_free(h->host_arena));
+        h->host_arena = nullptr; h->host_arena_bytes = 0;
+        const size_t want = (stats_b + plan_b + ((size_t)8 << 20)) & ~(((size_t)1 << 20) - 1);
+        HIPCHK(h, host_malloc(&h->host_arena, want, hipHostMallocDefault));
+        h->host_arena_bytes = want;
+    }
+    const uint32_t* stats = (const uint32_t*)h->host_arena;
+    HIPCHK(h, hipMemcpyAsync(h->host_arena, d_hist, hist_b + adl_b + flag_b, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     T[1] = now();
     PngTilePlan plan;
-    const size_t out_words = png_plan_tiles(n, stats.data(), stats.data() + (size_t)n * 512, stats.data() + (size_t)n * 1024, paths,
+    plan.arena = (char*)h->host_arena + stats_b;
+    plan.arena_bytes = h->host_arena_bytes - stats_b;
+    const size_t out_words = png_plan_tiles(n, stats, stats + (size_t)n * 512, stats + (size_t)n * 1024, paths,
                                             (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &plan);
     T[2] = now();
     if (plan.failed) return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)");
-    const size_t tb_b = plan.tb.size() * 4, hdr_b = plan.hdr.size() * 4, meta_b = plan.meta.size();
-    if ((rc = ensure_scratch(h, 3, tb_b + hdr_b + meta_b))) return rc;
+    const size_t tb_b = (size_t)n * 512 * 4, hdr_b = (size_t)n * 160 * 4;
+    if ((rc = ensure_scratch(h, 3, plan.upload_bytes))) return rc;
     if ((rc = ensure_scratch(h, 4, (out_words + 1) * 4))) return rc;
     uint8_t* d_tb = (uint8_t*)h->d_scratch[3];
     uint32_t* d_out = (uint32_t*)h->d_scratch[4];
-    HIPCHK(h, hipMemcpyAsync(d_tb, plan.tb.data(), tb_b, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(d_tb + tb_b, plan.hdr.data(), hdr_b, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(d_tb + tb_b + hdr_b, plan.meta.data(), meta_b, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(d_tb, plan.tb, plan.upload_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(d_out, 0, (out_words + 1) * 4, st));
     {
         Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0 + (double)out_words * 4.0);

@@ -523,6 +523,8 @@ hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* 
 // From the stats of `n` tiles: per tile the Huffman table / header / meta the emit kernel reads, the Adler-32 of the stream and the
 // size of its deflate bytes.  mode[t]: 0 = nothing to write (no path, or fully transparent), 1 = device stream, 2 = host encoder
 // (stored blocks would be smaller than this tile's Huffman block).  Returns the number of 32-bit words the output buffer needs.
+size_t png_plan_bytes(int n) { return (size_t)n * (512 * 4 + 160 * 4 + sizeof(TileMeta)); }
+
 size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
                       bool skip_transparent, bool force_host, PngTilePlan* plan) {
     plan->mode.assign(n, 0);
@@ -530,12 +532,21 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     plan->deflate_bytes.assign(n, 0);
     plan->eob.assign(n, 0);
     plan->eob_at.assign(n, 0);
-    plan->tb.assign((size_t)n * 512, 0);
-    plan->hdr.assign((size_t)n * 160, 0);
-    plan->meta.assign((size_t)n * sizeof(TileMeta), 0);
+    // the upload block: token tables and headers of tiles that emit nothing are never read (TileMeta::skip), so nothing is cleared
+    plan->upload_bytes = png_plan_bytes(n);
+    uint8_t* block = (uint8_t*)plan->arena;
+    if (!block || plan->arena_bytes < plan->upload_bytes) {
+        plan->own.resize(plan->upload_bytes);
+        block = plan->own.data();
+    }
+    plan->tb = (uint32_t*)block;
+    plan->hdr = plan->tb + (size_t)n * 512;
+    plan->meta = (uint8_t*)(plan->hdr + (size_t)n * 160);
     std::vector<uint32_t> words(n, 0);
     plan->failed = !parallel_for(n, [&](int t) {
-        TileMeta* m = (TileMeta*)plan->meta.data() + t;
+        TileMeta* m = (TileMeta*)plan->meta + t;
+        m->out_word = 0;
+        m->header_bits = 0;
         m->skip = 1;
         if (!paths[t] || (skip_transparent && !flags[t])) return;
         png::BlockCode bc;
@@ -563,12 +574,12 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     });
     size_t total = 0;
     for (int t = 0; t < n; ++t) {
-        TileMeta* m = (TileMeta*)plan->meta.data() + t;
+        TileMeta* m = (TileMeta*)plan->meta + t;
         m->out_word = total;
         total += words[t];
     }
     plan->out_word.resize(n);
-    for (int t = 0; t < n; ++t) plan->out_word[t] = ((const TileMeta*)plan->meta.data() + t)->out_word;
+    for (int t = 0; t < n; ++t) plan->out_word[t] = ((const TileMeta*)plan->meta + t)->out_word;
     return total;
 }
 

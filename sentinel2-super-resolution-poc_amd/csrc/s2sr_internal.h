@@ -230,14 +230,22 @@ struct PngTilePlan {
     std::vector<uint8_t> mode;            // 0 nothing to write, 1 device stream, 2 host encoder (stored blocks are smaller)
     std::vector<uint32_t> adler, deflate_bytes, eob;
     std::vector<uint64_t> eob_at, out_word;
-    std::vector<uint32_t> tb, hdr;        // [n][512] token table, [n][160] block header words (what the emit kernel reads)
-    std::vector<uint8_t> meta;            // [n] TileMeta (pngdev.hip)
+    // what the emit kernel reads: [n][512] token table, [n][160] block header words, [n] TileMeta (pngdev.hip) -- in this order in
+    // ONE block of upload_bytes: the caller's page-locked arena when it gave one (arena / arena_bytes), else `own`
+    uint32_t* tb = nullptr;
+    uint32_t* hdr = nullptr;
+    uint8_t* meta = nullptr;
+    size_t upload_bytes = 0;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<uint8_t> own;
     bool failed = false;                  // a planning thread threw (out of memory): the plan is incomplete
 };
 hipError_t launch_png_tile_stats(const uint8_t* d_tiles, int ntiles, uint32_t* d_hist, uint32_t* d_adler, uint32_t* d_flags, bool row_threads,
                                  hipStream_t st);
 hipError_t launch_png_tile_emit(const uint8_t* d_tiles, int ntiles, const void* d_meta, const uint32_t* d_tb, const uint32_t* d_hdr,
                                 uint32_t* d_out, bool row_threads, hipStream_t st);
+size_t png_plan_bytes(int n);      // bytes of the upload block of n tiles
 size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, const uint32_t* flags, const char* const* paths,
                       bool skip_transparent, bool force_host, PngTilePlan* plan);
 bool png_write_tile_file(const char* path, const uint32_t* words, uint32_t deflate_bytes, uint32_t eob, uint64_t eob_at, uint32_t adler,

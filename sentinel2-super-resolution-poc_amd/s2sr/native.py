@@ -117,6 +117,8 @@ _PROTOS = {
     "s2sr_tiles_base_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_void_p]),
     "s2sr_tiles_overview_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 6 + [C.c_void_p]),
     "s2sr_tiles_write_png": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_int32)]),
+    "s2sr_tiles_write_png_xyz": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.POINTER(C.c_int32)]),
     "s2sr_tiff_lzw_encode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_tiff_lzw_decode": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "s2sr_png_bound": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -655,6 +657,17 @@ class Engine:
         self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent) | (2 if host_encoder else 0) | (4 if row_threads else 0),
                                                    written.ctypes.data_as(C.POINTER(C.c_int32))),
                     "s2sr_tiles_write_png")
+        return written.reshape(ny, nx)
+
+    def tiles_write_png_xyz(self, nx: int, ny: int, directory, zoom: int, x0: int, y_rows, skip_transparent: bool = True) -> np.ndarray:
+        """tiles_write_png for the XYZ layout: tile (j, i) -> <directory>/<zoom>/<x0 + i>/<y_rows[j]>.png; the paths are built natively."""
+        rows = np.ascontiguousarray(y_rows, np.int32)
+        if rows.size != ny:
+            raise ValueError(f"{ny} tile rows, {rows.size} row numbers")
+        written = np.zeros(nx * ny, np.int32)
+        self._check(self._lib.s2sr_tiles_write_png_xyz(self._h, nx, ny, os.fsencode(str(directory)), zoom, x0, _ptr(rows),
+                                                       1 if skip_transparent else 0, written.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "s2sr_tiles_write_png_xyz")
         return written.reshape(ny, nx)
 
     def synchronize(self):
