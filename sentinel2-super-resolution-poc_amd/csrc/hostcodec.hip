@@ -76,8 +76,59 @@ extern "C" int s2sr_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, 
 // server/app/wow_sr.py:138-151).  One strip per call, so strips compress in parallel on host threads.
 // Worst case output is ~1.4x the input (12-bit codes for single bytes) + a few bytes: the caller
 // sizes dst as n*3/2 + 16.
+// The "literal" form of a TIFF LZW stream: every byte as its own 9-bit code, a ClearCode every 250 codes so that the decoder's
+// table never reaches the 10-bit switch (after a clear the first code adds nothing, each later one adds an entry: 258 + 249 = 507
+// < 511).  A valid LZW stream for every decoder -- it just never uses the dictionary -- of 1.13x the input, written at memory speed.
+// The SR outputs this path writes are 8-bit RGB with sensor-like texture: real LZW *expands* them (1.25 - 1.35x at ~135 MB/s per
+// thread: most lookups miss, every miss costs a probe and a 9..12-bit code for one byte), so on such strips this form is both the
+// smaller file and ~10x faster; s2sr_tiff_lzw_encode picks it per strip when a 16-KB sample expands under the dictionary coder.
+static int lzw_encode_literal(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
+    const size_t need = ((n + n / 250 + 3) * 9 + 7) / 8;
+    if (cap < need) return S2SR_E_CAPACITY;
+    size_t pos = 0;
+    uint64_t acc = 0;
+    int nacc = 0;
+    auto put9 = [&](uint32_t code) {
+        acc = (acc << 9) | code;
+        nacc += 9;
+        if (nacc >= 32) {
+            const uint32_t v = __builtin_bswap32((uint32_t)(acc >> (nacc - 32)));
+            memcpy(dst + pos, &v, 4);
+            pos += 4;
+            nacc -= 32;
+        }
+    };
+    size_t i = 0;
+    while (i < n) {
+        put9(256);
+        const size_t end = i + 250 < n ? i + 250 : n;
+        for (; i < end; ++i) put9(src[i]);
+    }
+    if (n == 0) put9(256);
+    put9(257);
+    while (nacc >= 8) { dst[pos++] = (uint8_t)(acc >> (nacc - 8)); nacc -= 8; }
+    if (nacc > 0) dst[pos++] = (uint8_t)(acc << (8 - nacc));
+    *out_n = pos;
+    return S2SR_OK;
+}
+
+static int lzw_encode_dictionary(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n);
+
 extern "C" int s2sr_tiff_lzw_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
     if ((!src && n) || !dst || !out_n) return S2SR_E_INVALID;
+    // which form?  The dictionary coder on a sample from the middle of the strip: if it cannot get the sample below 1.10x, the
+    // literal form (1.13x, ~10x faster) takes the strip.  Small strips go to the dictionary coder directly.
+    static const size_t kSample = 16384;
+    if (n >= 4 * kSample) {
+        uint8_t tmp[kSample * 3 / 2 + 16];
+        size_t m = 0;
+        if (lzw_encode_dictionary(src + (n / 2 & ~(size_t)63), kSample, tmp, sizeof tmp, &m) == S2SR_OK && m * 10 >= kSample * 11)
+            return lzw_encode_literal(src, n, dst, cap, out_n);
+    }
+    return lzw_encode_dictionary(src, n, dst, cap, out_n);
+}
+
+static int lzw_encode_dictionary(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
     // dictionary: open addressing over 32768 slots of (prefix code 12 | byte 8 | code 12) bits.  What costs is the probe
     // sequence of a MISS (on imagery most lookups miss: the string is new), so the table is kept nearly empty (load <= 0.12);
     // measured on a 786-KB strip of SR output: 8192 slots 7.7 ms, 16384 5.4, 32768 5.0 (r03's separate key / value arrays with

@@ -191,6 +191,21 @@ def test_lzw_encoder_roundtrip_and_libtiff_reads_it(tmp_path):
         assert tv[34737].startswith("WGS 84 / UTM zone 33N")
         back, g2 = rio.read_rgb_u8(p)
         assert np.array_equal(back, a) and g2.pixel_size == (2.5, 2.5)
+    # strips the dictionary coder would EXPAND (8-bit texture: most lookups miss, every miss is a 9..12-bit code for one byte) go
+    # out in the literal form -- every byte a 9-bit code, a ClearCode every 250: a valid LZW stream of 1.13x the input for any
+    # decoder, here libtiff's and the native one -- while compressible strips keep the dictionary form
+    noise = rng.integers(0, 256, 786432, dtype=np.uint8)
+    enc = native.tiff_lzw_encode(noise)
+    assert 1.12 < len(enc) / noise.size < 1.135 and native.tiff_lzw_decode(enc, noise.size) == noise.tobytes()
+    ramp = (np.arange(786432) // 300 % 256).astype(np.uint8)
+    assert len(native.tiff_lzw_encode(ramp)) < 0.2 * ramp.size
+    a = rng.integers(0, 256, (200, 500, 3), dtype=np.uint8)          # 96-KB strips of noise: literal form
+    a[130:] = 77                                                      # ... and the last strip a constant: dictionary form
+    p = tmp_path / "lit.tif"
+    rio.write_geotiff_rgb(p, a, geo)
+    assert p.stat().st_size < 1.14 * 130 * 1500 + 20000
+    assert np.array_equal(np.asarray(Image.open(p)), a)
+    assert np.array_equal(rio.read_rgb_u8(p)[0], a)
 
 
 def test_png_encoder_bands_form_one_stream():
