@@ -532,7 +532,8 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
     plan->deflate_bytes.assign(n, 0);
     plan->eob.assign(n, 0);
     plan->eob_at.assign(n, 0);
-    // the upload block: token tables and headers of tiles that emit nothing are never read (TileMeta::skip), so nothing is cleared
+    // the upload block: token tables and headers of tiles that emit nothing are never read (TileMeta::skip), so the block is not
+    // cleared as a whole (a page-locked arena that is reused holds the previous level's bytes); emitting tiles clear their header slot
     plan->upload_bytes = png_plan_bytes(n);
     uint8_t* block = (uint8_t*)plan->arena;
     if (!block || plan->arena_bytes < plan->upload_bytes) {
@@ -558,6 +559,7 @@ size_t png_plan_tiles(int n, const uint32_t* hist, const uint32_t* adler_rows, c
         m->skip = 0;
         m->header_bits = bc.header_bits;
         memcpy(&plan->tb[(size_t)t * 512], bc.tb, sizeof bc.tb);
+        memset(&plan->hdr[(size_t)t * 160], 0, 160 * 4);        // the kernel takes whole words: nothing stale behind the header's last bit
         memcpy(&plan->hdr[(size_t)t * 160], bc.header, (bc.header_bits + 7) / 8);
         // the end-of-block code is the last thing in the stream: the host ORs it in after the copy back (its offset is known here)
         plan->eob[t] = bc.eob;
