@@ -198,9 +198,38 @@ def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: O
     return b"".join(encode_png_pieces(img, level, band_rows, workers, strategy))
 
 
+def write_pieces(path: Path, pieces) -> None:
+    """The byte strings `pieces` one behind the other into `path`.  A 4096 x 4096 output is 60 - 90 MB of encoded strips and bands:
+    pushed through ONE write loop the copy into the page cache (fresh pages: allocate, zero, copy) took as long as all the
+    encoding on 16 threads; here the file is sized first and the big pieces land at their offsets from the host pool (os.pwrite
+    releases the GIL)."""
+    import os
+    sizes = [len(p) for p in pieces]
+    total = sum(sizes)
+    if total < (8 << 20) or len(pieces) < 4:
+        with open(path, "wb") as f:
+            f.writelines(pieces)
+        return
+    offs = [0] * len(pieces)
+    for i in range(1, len(pieces)):
+        offs[i] = offs[i - 1] + sizes[i - 1]
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fd, total)
+
+        def put(i):
+            mv, at = memoryview(pieces[i]), offs[i]
+            while len(mv):
+                n = os.pwrite(fd, mv, at)
+                mv, at = mv[n:], at + n
+        from . import hostpool
+        list(hostpool.pool().map(put, range(len(pieces))))
+    finally:
+        os.close(fd)
+
+
 def write_png(path: Path, rgb: np.ndarray) -> None:
-    with open(path, "wb") as f:
-        f.writelines(encode_png_pieces(rgb))
+    write_pieces(path, encode_png_pieces(rgb))
 
 
 def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoRef") -> None:
@@ -274,10 +303,8 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
             e += struct.pack("<I", val_pos + len(tail))
             tail += data + (b"\0" if len(data) & 1 else b"")
         ifd += e
-    with open(path, "wb") as f:
-        f.write(b"II" + struct.pack("<HI", 42, ifd_off))
-        for e in enc:
-            f.write(e)
-            if len(e) & 1:
-                f.write(b"\0")
-        f.write(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)
+    pieces = [b"II" + struct.pack("<HI", 42, ifd_off)]
+    for e in enc:
+        pieces.append(e if not len(e) & 1 else e + b"\0")
+    pieces.append(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)
+    write_pieces(path, pieces)
