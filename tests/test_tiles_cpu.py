@@ -63,8 +63,9 @@ def test_warp_plan_follows_the_projection():
     src = geo.Placement(600000.0, 5100000.0, 2.5, 2.5)
     crs = geo.CRS(32633)
     plan = tiles.plan_warp(400, 300, src, crs)
-    assert plan.step == 16 and plan.grid.dtype == np.float32
-    assert (plan.grid.shape[0] - 1) * 16 >= plan.out_h - 1 and (plan.grid.shape[1] - 1) * 16 >= plan.out_w - 1
+    st = plan.step
+    assert st == 64 and plan.grid.dtype == np.float32
+    assert (plan.grid.shape[0] - 1) * st >= plan.out_h - 1 and (plan.grid.shape[1] - 1) * st >= plan.out_w - 1
     # pixel count along the diagonal is preserved (GDAL's suggested-output rule)
     assert abs(np.hypot(plan.out_w, plan.out_h) - np.hypot(400, 300)) < 2.0
     # interpolating the node grid at an off-node pixel agrees with projecting that pixel directly
@@ -75,11 +76,26 @@ def test_warp_plan_follows_the_projection():
     sx, sy = crs.from_lonlat(lon, lat)
     u, v = (float(sx) - src.x0) / src.dx - 0.5, (src.y0 - float(sy)) / src.dy - 0.5
     g = plan.grid.astype(np.float64)
-    gi, gj, fi, fj = oy // 16, ox // 16, (oy % 16) / 16, (ox % 16) / 16
+    gi, gj, fi, fj = oy // st, ox // st, (oy % st) / st, (ox % st) / st
     top = g[gi, gj] + (g[gi, gj + 1] - g[gi, gj]) * fj
     bot = g[gi + 1, gj] + (g[gi + 1, gj + 1] - g[gi + 1, gj]) * fj
     ui, vi = top + (bot - top) * fi
     assert abs(ui - u) < 0.01 and abs(vi - v) < 0.01
+    # ... and on the raster size a job really warps (4096 x 4096 at 2.5 m), anywhere between the nodes, the interpolated source
+    # coordinate stays within a thousandth of a pixel of the projected one (the node spacing was chosen for that)
+    big = tiles.plan_warp(4096, 4096, src, crs)
+    rng = np.random.default_rng(0)
+    oy, ox = rng.integers(0, big.out_h, 3000), rng.integers(0, big.out_w, 3000)
+    X = big.placement.x0 + (ox + 0.5) * big.placement.dx
+    Y = big.placement.y0 - (oy + 0.5) * big.placement.dy
+    sx, sy = crs.from_lonlat(*geo.mercator_to_lonlat(X, Y))
+    u, v = (sx - src.x0) / src.dx - 0.5, (src.y0 - sy) / src.dy - 0.5
+    g = big.grid.astype(np.float64)
+    gi, gj, fi, fj = oy // st, ox // st, ((oy % st) / st)[:, None], ((ox % st) / st)[:, None]
+    top = g[gi, gj] + (g[gi, gj + 1] - g[gi, gj]) * fj
+    bot = g[gi + 1, gj] + (g[gi + 1, gj + 1] - g[gi + 1, gj]) * fj
+    uv = top + (bot - top) * fi
+    assert np.abs(uv[:, 0] - u).max() < 1e-3 and np.abs(uv[:, 1] - v).max() < 1e-3, (np.abs(uv[:, 0] - u).max(), np.abs(uv[:, 1] - v).max())
     # every corner of the source lands inside the output extent
     w, s, e, n = plan.placement.bounds(plan.out_w, plan.out_h)
     for cx, cy in ((src.x0, src.y0), (src.x0 + 1000.0, src.y0 - 750.0)):
