@@ -2021,7 +2021,11 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
     // file writes with an idle device).  All statistics kernels and their copies back are queued up front; then, group by group:
     // wait for the group's statistics, build its codes (host pool), queue its upload + emit kernel, and -- while that runs --
     // bring the PREVIOUS group's streams back and write its files.  Streams ping-pong between two device buffers.
-    const int ngroups = (flags & S2SR_PNG_SMALL_GROUPS) ? (n + 2) / 3 : (n <= 1536 ? 1 : (n + 2047) / 2048);   // (the flag: groups of 3, for the tests)
+    int ngroups = (flags & S2SR_PNG_SMALL_GROUPS) ? (n + 2) / 3 : (n <= 1536 ? 1 : (n + 2047) / 2048);   // (the flag: groups of 3, for the tests)
+    if (const char* e = getenv("S2SR_PNG_GROUP_TILES")) {      // A/B knob (tools/tiles_ab.py): tiles per group, 0 = the whole level as one
+        const int v = atoi(e);
+        ngroups = v <= 0 ? 1 : (n + v - 1) / v;
+    }
     const int gsz = (n + ngroups - 1) / ngroups;
     const size_t tile_stats_b = (512 + 512 + 1) * 4;                       // per tile: token histogram, row Adler pairs, any-alpha flag
     int rc;
