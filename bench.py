@@ -293,14 +293,14 @@ def job_leg(side: int = 1024) -> dict:
 def mfma_ceiling_leg(eng, device_index: int) -> dict:
     """What the matrix pipe sustains on THIS part, measured here (csrc/ceiling.hip through s2sr_debug_mfma_ceiling): a bare fp16
     32x32x16 MFMA loop, the same loop with its operands re-read from LDS at conv_trunk_f16's 0.75 KiB per MFMA, and that loop with
-    its LDS ring refilled by LDS-DMA at the kernel's bytes per FLOP -- each ~0.8 s behind a settling run, with the clock and socket
+    its LDS ring refilled by LDS-DMA at the kernel's bytes per FLOP -- each ~0.5 s behind a settling run, with the clock and socket
     power sampled meanwhile.  Outside the timed region; the spec peak (2.5 PFLOP/s at 2.4 GHz) stays `roofline.peak`."""
     out = {"note": "one workgroup per CU, 8 waves, random fp16 operands in (-1, 1); stages of 288 MFMAs / 216 ds_read_b128 / 48 KiB LDS-DMA per "
                    "workgroup as in conv_trunk_f16 conv1-4 (28 stages per workgroup = the MFMA work of one launch of 16 images); no epilogue, no stores",
            "stages_per_launch": 448}
     for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (5, "lds_dma_fed_kernel_mix"), (3, "lds_dma_fed_half_bytes"), (4, "lds_dma_fed_from_cache")):
         probe = eng.mfma_ceiling(mode, 448, 8)                         # settles the clock and sizes the timed run
-        launches = int(max(16, min(4000, (0.8e6 if mode <= 2 else 0.5e6) / max(probe["us_per_launch"], 1.0))))
+        launches = int(max(16, min(4000, (0.5e6 if mode in (0, 1, 2, 5) else 0.3e6) / max(probe["us_per_launch"], 1.0))))   # ~3 s for the six loops
         sampler = ClockSampler(device_index)
         sampler.start()
         r = eng.mfma_ceiling(mode, 448, launches)
