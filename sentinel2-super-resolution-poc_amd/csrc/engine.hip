@@ -174,7 +174,6 @@ struct s2sr_handle {
     StitchMaps stitch_sets[4];
     uint64_t stitch_clock = 0;
     hipEvent_t host_copy_ev = nullptr;          // s2sr_copy_to_host: orders the copy stream behind the caller's stream
-    bool ceiling_filled = false;                // s2sr_debug_mfma_ceiling: scratch[2] holds its operand data
     void* host_arena = nullptr;                 // page-locked host block of the tile-PNG stage (stats back, plan up): grown on demand, kept
     size_t host_arena_bytes = 0;
     // the banded post-process in progress on this handle (s2sr_pp_band_*_dev, enhance_impl): geometry, channel order, how far the
@@ -2055,6 +2054,10 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
         hipEvent_t ev_stats = nullptr, ev_emit = nullptr;
     };
     std::vector<Group> groups(ngroups);
+    struct EventsBack {          // the groups' events go back to the handle's pool on every way out
+        s2sr_handle* h; std::vector<Group>& gs;
+        ~EventsBack() { for (Group& G : gs) { if (G.ev_stats) h->ev_pool.push_back(G.ev_stats); if (G.ev_emit) h->ev_pool.push_back(G.ev_emit); } }
+    } events_back{h, groups};
     for (int g = 0; g < ngroups; ++g) {
         Group& G = groups[g];
         G.a = g * gsz;
@@ -2077,7 +2080,6 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
     std::atomic<int> failed{0};
     if (written) for (int t = 0; t < n; ++t) written[t] = 0;
     size_t total_words = 0, n_host = 0;
-    auto give_back = [&]() { for (Group& G : groups) { h->ev_pool.push_back(G.ev_stats); h->ev_pool.push_back(G.ev_emit); } };
 
     // group g: its streams back in batches through the two page-locked staging buffers (while one batch is framed, checksummed and
     // written from its buffer by the host threads, the next one is on the wire), then the few tiles the host encoder takes
@@ -2156,10 +2158,10 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
             G.out_words = png_plan_tiles(G.n, G.stats, G.stats + (size_t)G.n * 512, G.stats + (size_t)G.n * 1024, paths + G.a,
                                          (flags & S2SR_PNG_SKIP_TRANSPARENT) != 0, (flags & S2SR_PNG_HOST_ENCODER) != 0, &G.plan);
             t_plan += now() - t1;
-            if (G.plan.failed) { give_back(); return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)"); }
+            if (G.plan.failed) { return fail(h, S2SR_E_IO, "planning the tile streams failed (an encoder thread ran out of memory)"); }
             total_words += G.out_words;
             const int oslot = 4 + (g & 1);                       // the group's stream buffer: scratch 4 / 5 in turn
-            if ((rc = ensure_scratch(h, oslot, (G.out_words + 1) * 4))) { give_back(); return rc; }
+            if ((rc = ensure_scratch(h, oslot, (G.out_words + 1) * 4))) return rc;
             uint32_t* d_out = (uint32_t*)h->d_scratch[oslot];
             HIPCHK(h, hipMemcpyAsync(G.d_tables, G.plan.tb, G.plan.upload_bytes, hipMemcpyHostToDevice, st));
             HIPCHK(h, hipMemsetAsync(d_out, 0, (G.out_words + 1) * 4, st));
@@ -2177,12 +2179,11 @@ static int tiles_write_png_locked(s2sr_handle* h, int32_t nx, int32_t ny, const 
             HIPCHK(h, hipEventSynchronize(P.ev_emit));           // the copy stream may read the group's streams
             double t1 = now();
             t_wait += t1 - t0;
-            if ((rc = write_group(P, (const uint32_t*)h->d_scratch[4 + ((g - 1) & 1)]))) { give_back(); return rc; }
+            if ((rc = write_group(P, (const uint32_t*)h->d_scratch[4 + ((g - 1) & 1)]))) return rc;
             t_files += now() - t1;
         }
     }
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
-    give_back();
     if (timing)
         fprintf(stderr, "[s2sr png] %d tiles in %d group(s) (%zu on the host encoder), %.1f ms: waiting for the device %.1f, Huffman codes %.1f, "
                 "streams (%.0f MB) back in batches + files %.1f (of which host-encoded tiles %.1f)\n", n, ngroups, n_host, now() - t_begin, t_wait,
@@ -2368,7 +2369,6 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
     const size_t src_bytes = (size_t)336 << 20;          // what a conv1-4 launch of 16 images fills its rings with; larger than L2 + MALL
-    const bool fresh = h->scratch_bytes[2] < src_bytes || !h->ceiling_filled;
     int rc = ensure_scratch(h, 2, src_bytes);
     if (rc) return rc;
     const size_t sink_bytes = (size_t)ncu * 512 * 4, store_bytes = (size_t)64 << 20;      // mode 5 streams its stores through 64 MB
@@ -2376,8 +2376,8 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     char* d_store = (char*)h->d_scratch[3] + sink_bytes;
     hipStream_t st = h->stream;
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
-    HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, fresh, (float*)h->d_scratch[3], ncu, stages, d_store, store_bytes, st));
-    h->ceiling_filled = true;
+    HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, true /* fill the operands: 0.1 ms */, (float*)h->d_scratch[3], ncu, stages, d_store,
+                                  store_bytes, st));
     for (int i = 0; i < launches / 4; ++i)
         HIPCHK(h, launch_mfma_ceiling(mode, (char*)h->d_scratch[2], src_bytes, false, (float*)h->d_scratch[3], ncu, stages, d_store, store_bytes, st));
     HIPCHK(h, hipEventRecord(e0, st));
@@ -2387,7 +2387,6 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
     h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
-    h->ceiling_filled = false;                            // scratch[2] is anybody's again
     if (flop_per_launch) *flop_per_launch = mfma_ceiling_flop_per_launch(ncu, stages);
     if (dma_bytes_per_launch) *dma_bytes_per_launch = mfma_ceiling_dma_bytes_per_launch(mode, ncu, stages);
     return S2SR_OK;
