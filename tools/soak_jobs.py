@@ -34,7 +34,7 @@ georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (
                      rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
 rng = np.random.default_rng(0)
 inputs = []
-for i, (h, w) in enumerate([(256, 256), (300, 421), (512, 512), (97, 640), (700, 530), (64, 64)]):
+for i, (h, w) in enumerate([(256, 256), (300, 421), (512, 512), (97, 640), (700, 530), (64, 64), (1100, 1300)]):      # the last: 30 windows in two chunks -- the band-wise job route (r05)
     yy, xx = np.mgrid[0:h, 0:w]
     rgb = np.stack([110 + 70 * np.sin(xx / 23.0 + c) * np.cos(yy / 17.0) + rng.integers(-12, 13, (h, w)) for c in range(3)], -1)
     p = tmp / f"in{i}.tif"
