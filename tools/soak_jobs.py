@@ -99,7 +99,10 @@ with contextlib.redirect_stdout(io.StringIO()):        # the reference's progres
     while any(t.is_alive() for t in ts):
         time.sleep(min(20.0, max(0.5, stop_at - time.time())))
         marks.append((time.time() - t0, sum(counts), *state()))
-        print(f"  {marks[-1][0]:6.0f} s  {marks[-1][1]:5d} jobs  free device {marks[-1][2]:8.0f} MiB  host RSS {marks[-1][3]:7.0f} MiB", file=sys.stderr)
+        from s2sr import native as _n
+        pp = _n.pinned_pool
+        print(f"  {marks[-1][0]:6.0f} s  {marks[-1][1]:5d} jobs  free device {marks[-1][2]:8.0f} MiB  host RSS {marks[-1][3]:7.0f} MiB  "
+              f"page-locked pool: {pp._total >> 20} MiB alive, {pp._idle >> 20} idle, hits {pp.hits} misses {pp.misses} refused {pp.refused}", file=sys.stderr)
     for t in ts:
         t.join()
 f1, r1 = state()
