@@ -80,7 +80,9 @@ def worker(t):
 
 
 def state():
-    torch.cuda.synchronize()
+    # (no torch.cuda.synchronize() here: a device-wide call from this thread while a worker's handle captures a graph is refused by
+    # the runtime IN THIS THREAD and voids that capture -- INTEGRATION.md "Threads"; r05's first long run died of exactly that,
+    # in the monitor, 100 s in)
     return torch.cuda.mem_get_info()[0] / 2**20, psutil.Process().memory_info().rss / 2**20
 
 
