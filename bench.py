@@ -692,22 +692,28 @@ def main():
         # 256/10 window plan), seed 4321: 4096x4096 (256 windows of 276x276) and the size the reference's fetch
         # step really clips to, 1024x1024 (up42_client.py:571-573: 16 windows)
         tile_rate = B * a.steps / dt                                      # tiles per second of the headline
-        for key, n in (("aoi", aoi_n), ("aoi_1024", 1024)):
+        # ("aoi_tile512": BASELINE configs[2] names 512x512 tiles; the reference's plan is 256/10 -- the same image on the 512/10 plan,
+        # 64 windows of 532x532, a throughput-only option: parity is asserted at the reference's defaults)
+        for key, n, tsz in (("aoi", aoi_n, 256), ("aoi_1024", 1024, 256), ("aoi_tile512", aoi_n, 512)):
             aoi = aoi_image(n)
             if key == "aoi":
                 eng.enhance_u8(aoi[:1024, :1024])   # warm-up: workspace for the window mosaics
-            eng.enhance_u8(aoi)                     # first sighting of each chunk: direct launches
-            eng.enhance_u8(aoi)                     # second sighting: each chunk's hipGraph is captured
+            eng.enhance_u8(aoi, tile=tsz)           # first sighting of each chunk: direct launches
+            eng.enhance_u8(aoi, tile=tsz)           # second sighting: each chunk's hipGraph is captured
             reps = 1 if n > 2048 else 5
             t0 = time.perf_counter()
             for _ in range(reps):
-                out = eng.enhance_u8(aoi)           # steady state: graph replays
+                out = eng.enhance_u8(aoi, tile=tsz)  # steady state: graph replays
             dta = (time.perf_counter() - t0) / reps
-            nwin = len(native.plan_tiles(n, n, 256, 10))
+            wins = native.plan_tiles(n, n, tsz, 10)
+            nwin, wsz = len(wins), wins[0].y2 - wins[0].y1
             sec[key] = {"value": round(16 * n * n / 1e6 / dta, 1), "unit": "SR-MP/s", "seconds": round(dta, 4),
                         "workload": f"{n}x{n}x3 u8 host image -> {4 * n}x{4 * n} u8 host image through s2sr_enhance_u8, "
-                                    f"reference plan 256/10: {nwin} windows of 276x276, {a.precision} mode; includes H2D / D2H and the stitch",
-                        "ideal_at_batch_rate_s": round(nwin * (276 * 276) / (256 * 256) / tile_rate, 4)}
+                                    f"plan {tsz}/10{' (the reference default)' if tsz == 256 else ''}: {nwin} windows of {wsz}x{wsz}, {a.precision} mode; includes H2D / D2H and the stitch",
+                        "ideal_at_batch_rate_s": round(nwin * (wsz * wsz) / (256 * 256) / tile_rate, 4)}
+            if key == "aoi_tile512":
+                del out
+                continue
             if key == "aoi":
                 ref_out = out
                 # the same image as an /api/wow job's device work (s2sr_enhance_job_u8: RGB in, swap, net, swap, post-process, RGB

@@ -16,7 +16,7 @@ for f in sys.argv[1:]:
             print(f"   fp8: {s['fp8']['value']} SR-MP/s {s['fp8']['ms_per_step']} ms/step frac {s['fp8']['roofline']['frac']}")
         if "aoi" in s:
             print(f"   aoi: {s['aoi']['value']} SR-MP/s in {s['aoi']['seconds']} s (ideal {s['aoi']['ideal_at_batch_rate_s']} s); 1 tile {s.get('latency_ms_1tile')} ms")
-        for k in ("aoi_job_plain", "aoi_job_enhance_crops", "aoi_1024", "aoi_dist_world1", "enhance_crops_b64", "job_1024", "ref_recorded_job", "mfma_ceiling"):
+        for k in ("aoi_tile512", "aoi_job_plain", "aoi_job_enhance_crops", "aoi_1024", "aoi_dist_world1", "enhance_crops_b64", "job_1024", "ref_recorded_job", "mfma_ceiling"):
             if k in s:
                 print(f"   {k}: " + "  ".join(f"{kk}={vv}" for kk, vv in s[k].items() if kk != "workload"))
         if "latency_ms_64x64" in s:
