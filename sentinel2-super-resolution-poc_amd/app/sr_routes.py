@@ -110,12 +110,52 @@ class GpuAdmission:
 
 
 def _parse_multipart(content_type: str, body: bytes) -> dict:
-    """multipart/form-data -> {field: (filename or None, bytes)}.  (python-multipart, which FastAPI's
-    File()/Form() need, is not a dependency of this build; the stdlib MIME parser does the same job.)"""
+    """multipart/form-data -> {field: (filename or None, bytes)}.  (python-multipart, which FastAPI's File()/Form() need, is not a
+    dependency of this build.)  The body is cut at its boundary lines with bytes.find -- an upload is mostly one binary part, and
+    the stdlib MIME parser (r04's route here) walks it line by line: 6-16 ms for a 0.4-MB image, about a second for the 50 MB the
+    handler admits; only the few header lines of each part go through the email package.  Bodies this splitter cannot make sense
+    of (no boundary parameter, LF-only line ends) still take the stdlib route."""
     if "multipart/form-data" not in (content_type or "").lower():
         raise HTTPException(status_code=422, detail="expected multipart/form-data with an `image` file field")
-    msg = BytesParser().parsebytes(b"Content-Type: " + content_type.encode() + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
+    hdr = BytesParser().parsebytes(b"Content-Type: " + content_type.encode("latin-1", "replace") + b"\r\n\r\n")
+    boundary = hdr.get_param("boundary")
     out = {}
+    if boundary:
+        delim = b"--" + boundary.encode("latin-1", "replace")
+        pos = body.find(delim)
+        while pos >= 0:
+            pos += len(delim)
+            if body[pos:pos + 2] == b"--":                       # the closing delimiter
+                return out
+            eol = body.find(b"\r\n", pos)                        # (transport padding may follow the delimiter)
+            if eol < 0:
+                break
+            head_end = body.find(b"\r\n\r\n", eol)
+            nxt = eol
+            while True:                                          # the next delimiter LINE: "--boundary" then "--" or (padding and) CRLF
+                nxt = body.find(b"\r\n" + delim, nxt)
+                if nxt < 0:
+                    break
+                tail = body[nxt + 2 + len(delim):nxt + 2 + len(delim) + 80]
+                if tail[:2] == b"--" or tail.lstrip(b" \t")[:2] == b"\r\n":
+                    break
+                nxt += 2
+            if head_end < 0 or nxt < 0 or head_end > nxt:
+                break
+            part = BytesParser().parsebytes(body[eol + 2:head_end] + b"\r\n\r\n")
+            name = part.get_param("name", header="content-disposition")
+            if name:
+                data = body[head_end + 4:nxt]
+                cte = (part.get("content-transfer-encoding") or "").strip().lower()
+                if cte in ("base64", "quoted-printable"):        # (RFC 7578 deprecates these for form data; honoured all the same)
+                    import base64
+                    import quopri
+                    data = base64.b64decode(data) if cte == "base64" else quopri.decodestring(data)
+                out[name] = (part.get_filename(), data)
+            pos = nxt + 2
+        if out:
+            return out
+    msg = BytesParser().parsebytes(b"Content-Type: " + content_type.encode("latin-1", "replace") + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
     if msg.is_multipart():
         for part in msg.get_payload():
             name = part.get_param("name", header="content-disposition")

@@ -240,3 +240,39 @@ def test_gpu_admission_two_devices():
     assert got == [0, 1, 0, 1, None] and adm2.snapshot()["pending"] == ["j4"]
     with pytest.raises(ValueError):
         GpuAdmission([0], jobs_per_device=0)
+
+
+def test_multipart_splitter_matches_the_mime_parser():
+    """/api/enhance takes its upload apart with a boundary splitter (app.sr_routes._parse_multipart: bytes.find, the email package
+    only for the few header lines of a part) instead of walking a multi-megabyte binary body line by line.  Same fields as the
+    stdlib MIME parser on well-formed bodies -- quoted and unquoted boundary parameters, browser-style boundaries, file names with
+    spaces, payloads that contain CRLFs, the delimiter text without its line break and a delimiter PREFIX at a line start --
+    and the stdlib route is still taken for bodies the splitter cannot read (LF-only line ends)."""
+    import os
+    from email.parser import BytesParser
+    from app.sr_routes import _parse_multipart
+
+    def stdlib(ct, body):
+        msg = BytesParser().parsebytes(b"Content-Type: " + ct.encode() + b"\r\nMIME-Version: 1.0\r\n\r\n" + body)
+        return {p.get_param("name", header="content-disposition"): (p.get_filename(), p.get_payload(decode=True) or b"") for p in msg.get_payload()}
+
+    blob = os.urandom(300_000)
+    for bnd in ("BoUnD", "----WebKitFormBoundary7MA4YWxkTrZu0gW"):
+        body = (f'--{bnd}\r\nContent-Disposition: form-data; name="model"\r\n\r\nrealesrgan_anime\r\n--{bnd}\r\n'
+                f'Content-Disposition: form-data; name="image"; filename="my plate.png"\r\nContent-Type: image/png\r\n\r\n').encode() \
+            + blob + f"\r\n--{bnd}--\r\n".encode()
+        for ct in (f"multipart/form-data; boundary={bnd}", f'multipart/form-data; boundary="{bnd}"'):
+            got = _parse_multipart(ct, body)
+            assert got["model"] == (None, b"realesrgan_anime") and got["image"] == ("my plate.png", blob)
+    tricky = b"abc--BoUnD\r\nxyz\r\n\r\n--BoUnDx" + blob[:100] + b"\r\n--BoUnD-not a delimiter\r\n"
+    body = (b'--BoUnD\r\nContent-Disposition: form-data; name="a"\r\n\r\n1\r\n--BoUnD  \r\n'
+            b'Content-Disposition: form-data; name="image"; filename="t.bin"\r\n\r\n' + tricky + b"\r\n--BoUnD--\r\n")
+    got = _parse_multipart("multipart/form-data; boundary=BoUnD", body)
+    assert got["image"] == ("t.bin", tricky) and got["a"] == (None, b"1")
+    text = b'--B\r\nContent-Disposition: form-data; name="x"\r\n\r\nhello\r\nworld\r\n--B\r\nContent-Disposition: form-data; name="y"; filename="f"\r\n\r\n\r\n--B--\r\n'
+    assert _parse_multipart("multipart/form-data; boundary=B", text) == stdlib("multipart/form-data; boundary=B", text) == {"x": (None, b"hello\r\nworld"), "y": ("f", b"")}
+    assert _parse_multipart("multipart/form-data; boundary=B", b'--B\nContent-Disposition: form-data; name="model"\n\nx\n--B--\n') == {"model": (None, b"x")}
+    import pytest
+    from fastapi import HTTPException
+    with pytest.raises(HTTPException):
+        _parse_multipart("application/json", b"{}")
