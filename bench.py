@@ -281,7 +281,8 @@ def job_leg(side: int = 1024) -> dict:
                 "tile_pyramid_ms": round(t_tiles, 1), "tiles": ntiles,
                 "tile_pyramid_stages_ms": {k: round(v * 1e3, 1) for k, v in tiling.LAST_STATS.items()},
                 "workload": f"process_wow_sr on a {side}x{side} UTM GeoTIFF (enhance_crops on, tile 256 / pad 10) -> {4 * side}x{4 * side} LZW GeoTIFF + PNG "
-                            "on disk; then process_raster_to_tiles z10..18 of the SR GeoTIFF (EPSG:3857 warp, RGBA PNG tiles); best of 3 warm runs"}
+                            "on disk; then process_raster_to_tiles z10..18 of the SR GeoTIFF (EPSG:3857 warp, RGBA PNG tiles) as run_wow_job calls it right behind the job "
+                            "(main.py:347-359): the raster the job has just written comes from this process's memory, not from the LZW file (stage `read`); best of 3 warm runs"}
     finally:
         if old_dir is None:
             os.environ.pop("S2SR_MODEL_DIR", None)

@@ -59,7 +59,7 @@ def apply_farm_sr(input_path: Path, output_path: Path, scale: int = 4) -> Tuple[
     output_png = output_path.with_suffix(".png")
     if georef is not None:
         final_output = output_path.with_suffix(".tif")
-        rio.write_outputs(final, output_png, final_output, georef.scaled(scale))
+        rio.write_outputs(final, output_png, final_output, georef.scaled(scale), remember=True)
     else:
         final_output = output_png
         rio.write_png(output_png, final)

@@ -100,7 +100,9 @@ _GDAL_TYPE = {"uint8": "Byte", "uint16": "UInt16", "int16": "Int16", "uint32": "
 
 
 def _read(path: Path):
-    arr, tags = tiff_lite.read_tiff(path)
+    # a raster this process wrote a moment ago and nobody touched since (a job's sr_tif, main.py:347-359) comes from memory
+    hit = rio.recall_written(path)
+    arr, tags = hit if hit is not None else tiff_lite.read_tiff(path)
     place = geo.placement_from_tags(tags)
     if place is None:
         raise ValueError(f"{path}: no north-up georeferencing (tiepoint + pixel scale) in the GeoTIFF tags")

@@ -72,7 +72,7 @@ def apply_wow_sr(input_path: Path, output_path: Path, enhance_crops: bool = True
     if georef is not None:
         final_output = output_path.with_suffix(".tif")
         # the two encoders side by side (both are thread pools over strips / bands of the same array)
-        rio.write_outputs(output_rgb, output_png, final_output, georef.scaled(scale))   # pixel size / scale (:128-135)
+        rio.write_outputs(output_rgb, output_png, final_output, georef.scaled(scale), remember=True)   # pixel size / scale (:128-135)
     else:
         final_output = output_png
         rio.write_png(output_png, output_rgb)

@@ -10,6 +10,8 @@ uint16, strips or tiles, LZW / Deflate / none, predictor 2, classic or BigTIFF).
 """
 from __future__ import annotations
 
+import os
+import threading
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Dict, Optional, Tuple
@@ -210,9 +212,57 @@ def write_png(path: Path, rgb: np.ndarray) -> None:
     write_pieces(path, encode_png_pieces(rgb))
 
 
-def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoRef") -> None:
+# ---- the rasters this process wrote last, for the stage that reads them right back ---------------------------------------------
+# A /api/wow job writes <stem>_wow_sr.tif and then hands that PATH to the tiler (reference main.py:347-359: process_wow_sr, then
+# process_raster_to_tiles on its sr_tif): the pyramid's first 24 ms were the LZW decode of the 50 MB that had been an array in this
+# process a moment before.  On request (`remember=True`: the job's writers, whose array nobody writes to again) write_geotiff_rgb
+# keeps a read-only view of the last two arrays it wrote, keyed by the file's resolved path and valid while the file's size and
+# mtime are what they were after the write; `recall_written` hands them to app.tiling.  Nothing else reads through it; a file touched by anyone else is read from disk like any other.
+_WRITTEN: Dict[str, tuple] = {}
+_WRITTEN_LOCK = threading.Lock()
+
+
+def _remember_written(path, rgb: np.ndarray, georef: "GeoRef") -> None:
+    try:
+        key = str(Path(path).resolve())
+        st = os.stat(key)
+        view = rgb.view()
+        view.flags.writeable = False
+        tags = {t: (tuple(v) if isinstance(v, (tuple, list)) else (v,)) for t, v in georef.tags.items()}
+        with _WRITTEN_LOCK:
+            _WRITTEN.pop(key, None)
+            while len(_WRITTEN) >= 2:
+                _WRITTEN.pop(next(iter(_WRITTEN)))
+            _WRITTEN[key] = (st.st_mtime_ns, st.st_size, view, tags)
+    except OSError:
+        pass
+
+
+def recall_written(path):
+    """-> (uint8 [H, W, 3] read-only array, {tag: values}) when `path` is a GeoTIFF this process wrote and nobody has touched since; else None."""
+    try:
+        key = str(Path(path).resolve())
+        st = os.stat(key)
+    except OSError:
+        return None
+    with _WRITTEN_LOCK:
+        hit = _WRITTEN.get(key)
+        if hit is None:
+            return None
+        if hit[0] != st.st_mtime_ns or hit[1] != st.st_size:
+            _WRITTEN.pop(key, None)
+            return None
+        return hit[2], dict(hit[3])
+
+
+def forget_written() -> None:
+    with _WRITTEN_LOCK:
+        _WRITTEN.clear()
+
+
+def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoRef", remember: bool = False) -> None:
     """The GeoTIFF and the PNG of one job (wow_sr.py:126-164) written side by side: two threads, each a pool over strips /
-    bands of the same array (zlib and the native LZW encoder release the GIL)."""
+    bands of the same array (zlib and the native LZW encoder release the GIL).  remember: see write_geotiff_rgb."""
     import threading
     err = []
 
@@ -221,7 +271,7 @@ def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoR
             fn(*a)
         except BaseException as e:      # surfaced below: a failed writer must fail the job
             err.append(e)
-    t = threading.Thread(target=run, args=(write_geotiff_rgb, tif_path, rgb, georef))
+    t = threading.Thread(target=run, args=(write_geotiff_rgb, tif_path, rgb, georef, 64, remember))
     t.start()
     run(write_png, png_path, rgb)
     t.join()
@@ -229,11 +279,12 @@ def write_outputs(rgb: np.ndarray, png_path: Path, tif_path: Path, georef: "GeoR
         raise err[0]
 
 
-def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_strip: int = 64) -> None:
+def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_strip: int = 64, remember: bool = False) -> None:
     """uint8 RGB, LZW compressed (compress="lzw", wow_sr.py:138-151) with the geo tags.  Classic
     little-endian TIFF, chunky RGB strips; the strips are LZW-encoded by the native library on a
     thread pool (the SR outputs are tens of megapixels; a single-threaded encoder is what a job would
-    otherwise wait for)."""
+    otherwise wait for).  remember: the caller will not write to `rgb` again -- a view of it is kept for the stage that reads this
+    file right back (`recall_written`)."""
     import os
     import struct
     from concurrent.futures import ThreadPoolExecutor
@@ -286,3 +337,5 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
         pieces.append(e if not len(e) & 1 else e + b"\0")
     pieces.append(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)
     write_pieces(path, pieces)
+    if remember:
+        _remember_written(path, rgb, georef)

@@ -206,3 +206,44 @@ def test_oracle_against_gdal_golden(golden_dir):
                     ours[f"tile_{lv.zoom}_{lv.tminx + i}_{geo.xyz_row(lv.tmaxy - j, lv.zoom)}"] = cur[j, i]
         prev, prev_lv = cur, lv
     compare_with_gdal(g, ours)
+
+
+def test_tiler_takes_the_raster_a_job_just_wrote_from_memory(tmp_path):
+    """A job writes <stem>_wow_sr.tif and hands the PATH to the tiler (reference main.py:347-359).  The job's writers ask
+    rasterio_lite to remember the array (`remember=True`: they never write to it again); app.tiling._read then gets it from
+    memory -- same pixels and geo tags as the file decodes to -- as long as the file's size and mtime are what the write left; a file
+    somebody touched, a file written without the request, and a file this process did not write are read from disk."""
+    import os
+    import time
+    import app.tiling as tiling
+    from s2sr import rasterio_lite as rio
+    from s2sr import tiff_lite
+    rio.forget_written()
+    rgb = np.random.default_rng(2).integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                         rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+    p = tmp_path / "job_wow_sr.tif"
+    rio.write_outputs(rgb, tmp_path / "job_wow_sr.png", p, georef, remember=True)
+    hit = rio.recall_written(p)
+    assert hit is not None and hit[0].base is not None and not hit[0].flags.writeable
+    disk, dtags = tiff_lite.read_tiff(p)
+    assert np.array_equal(hit[0], disk)
+    for t in (rio.TAG_PIXEL_SCALE, rio.TAG_TIEPOINT, rio.TAG_GEOKEYS):
+        assert tuple(hit[1][t]) == tuple(dtags[t])
+    a_mem = tiling._read(p)
+    rio.forget_written()
+    a_disk = tiling._read(p)
+    assert np.array_equal(a_mem[0], a_disk[0]) and a_mem[2] == a_disk[2] and str(a_mem[3]) == str(a_disk[3])
+    # not asked to remember -> nothing kept; touched by somebody else -> dropped
+    rio.write_geotiff_rgb(tmp_path / "plain.tif", rgb, georef)
+    assert rio.recall_written(tmp_path / "plain.tif") is None
+    rio.write_geotiff_rgb(p, rgb, georef, remember=True)
+    assert rio.recall_written(p) is not None
+    time.sleep(0.02)
+    os.utime(p, None)
+    assert rio.recall_written(p) is None and rio.recall_written(tmp_path / "absent.tif") is None
+    # at most two rasters are kept
+    for k in range(3):
+        rio.write_geotiff_rgb(tmp_path / f"k{k}.tif", rgb, georef, remember=True)
+    assert rio.recall_written(tmp_path / "k0.tif") is None and rio.recall_written(tmp_path / "k2.tif") is not None
+    rio.forget_written()
