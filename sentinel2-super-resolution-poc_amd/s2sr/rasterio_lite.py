@@ -132,7 +132,7 @@ def _adler32_combine(a1: int, a2: int, len2: int) -> int:
 
 
 def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None,
-                      strategy: Optional[int] = None) -> list:
+                      strategy: Optional[int] = None, stream: bool = False):
     """HxWx3 (RGB) or HxWx4 (RGBA) uint8 -> the PNG file as a list of byte strings to be written in order.  The SR outputs are
     tens of megapixels and PNG deflate is what a job's writer spends its time in, so the image is cut into bands that are
     filtered (Sub) and deflated in parallel, each band ending on a sync flush so that the pieces concatenate into one valid zlib
@@ -141,7 +141,9 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
     Encoder settings = what `cv2.imwrite(path, img)` uses when the reference calls it without parameters (wow_sr.py:156,163;
     OpenCV 4.x grfmt_png.cpp: filter Sub, Z_BEST_SPEED, strategy Z_RLE).  With the defaults the bands go through the native
     encoder (csrc/pngenc.hip: the same filter and run-length matching, 2-3x zlib's speed); `level` / `strategy` other than the
-    defaults select zlib.  Any setting decodes to the same pixels."""
+    defaults select zlib.  Any setting decodes to the same pixels.  stream: a generator over the same pieces -- a band's chunk is
+    handed out as soon as it and its predecessors are deflated (the bands run on the shared host pool), so a writer's loop runs under
+    the deflating of the bands behind it."""
     import struct
     import zlib
     from concurrent.futures import ThreadPoolExecutor
@@ -175,24 +177,35 @@ def encode_png_pieces(img: np.ndarray, level: int = 1, band_rows: int = 128, wor
         return piece, zlib.adler32(raw), raw.size
 
     work = work_native if use_native else work_zlib
-    if len(bands) > 1 and workers is None:
-        from . import hostpool
-        parts = list(hostpool.pool().map(work, range(len(bands))))
-    elif len(bands) > 1 and workers > 1:
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            parts = list(pool.map(work, range(len(bands))))
-    else:
-        parts = [work(i) for i in range(len(bands))]
-    adler = 1
-    for _, a, ln in parts:
-        adler = _adler32_combine(adler, a, ln)
 
     def chunk(kind: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
 
-    # signature, IHDR, the bands' IDAT chunks, one small IDAT with the stream's Adler-32 (IDAT payloads concatenate), IEND
-    return ([b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))] +
-            [p for p, _, _ in parts] + [chunk(b"IDAT", struct.pack(">I", adler)) + chunk(b"IEND", b"")])
+    head = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))
+
+    def pieces():
+        # signature, IHDR, the bands' IDAT chunks in order, one small IDAT with the stream's Adler-32 (IDAT payloads concatenate), IEND
+        yield head
+        adler = 1
+        if len(bands) > 1 and workers is None:
+            from . import hostpool
+            it = hostpool.pool().map(work, range(len(bands)))
+            for p, a, ln in it:
+                adler = _adler32_combine(adler, a, ln)
+                yield p
+        elif len(bands) > 1 and workers > 1:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                for p, a, ln in pool.map(work, range(len(bands))):
+                    adler = _adler32_combine(adler, a, ln)
+                    yield p
+        else:
+            for i in range(len(bands)):
+                p, a, ln = work(i)
+                adler = _adler32_combine(adler, a, ln)
+                yield p
+        yield chunk(b"IDAT", struct.pack(">I", adler)) + chunk(b"IEND", b"")
+
+    return pieces() if stream else list(pieces())
 
 
 def encode_png(img: np.ndarray, level: int = 1, band_rows: int = 128, workers: Optional[int] = None, strategy: Optional[int] = None) -> bytes:
@@ -204,12 +217,21 @@ def write_pieces(path: Path, pieces) -> None:
     """The byte strings `pieces` one behind the other into `path`.  One write loop: measured on the 16-CPU GPU box, 43 MB of encoded
     strips go out in 5.0 ms this way and in 5.9 ms as positional writes from the host pool into a pre-sized file
     (tools/write_probe.py, r05) -- the page cache takes 8 GB/s from one thread; what a job's writers wait for is the encoders."""
-    with open(path, "wb") as f:
-        f.writelines(pieces)
+    ok = False
+    try:
+        with open(path, "wb") as f:
+            f.writelines(pieces)
+        ok = True
+    finally:
+        if not ok:                 # (the pieces may be a generator that still encodes: no half-written file stays behind its failure)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
 
 
 def write_png(path: Path, rgb: np.ndarray) -> None:
-    write_pieces(path, encode_png_pieces(rgb))
+    write_pieces(path, encode_png_pieces(rgb, stream=True))       # (a generator: bands reach the file while later bands deflate)
 
 
 # ---- the rasters this process wrote last, for the stage that reads them right back ---------------------------------------------
@@ -297,45 +319,60 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
         raise ValueError(f"expected HxWx3, got {rgb.shape}")
     strips = [(y, min(h, y + rows_per_strip)) for y in range(0, h, rows_per_strip)]
     from . import hostpool
-    enc = list(hostpool.pool().map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips))
-    offs, pos = [], 8
-    for e in enc:
-        offs.append(pos)
-        pos += len(e) + (len(e) & 1)
-    if pos >= (1 << 32) - (1 << 20):
-        raise ValueError("output exceeds the 4 GiB of a classic TIFF")
-    ent = [(256, 4, (w,)), (257, 4, (h,)), (258, 3, (8, 8, 8)), (259, 3, (5,)), (262, 3, (2,)), (273, 4, tuple(offs)),
-           (277, 3, (3,)), (278, 4, (rows_per_strip,)), (279, 4, tuple(len(e) for e in enc)), (284, 3, (1,)), (339, 3, (1, 1, 1))]
-    for tag, val in georef.tags.items():
-        if tag == TAG_GEOKEYS:
-            ent.append((tag, 3, tuple(int(v) for v in val)))
-        elif tag == TAG_GEOASCII:
-            ent.append((tag, 2, val if isinstance(val, str) else str(val)))
-        else:
-            ent.append((tag, 12, tuple(float(v) for v in val)))
-    ent.sort(key=lambda e: e[0])
-    fmt = {3: "H", 4: "I", 12: "d"}
-    ifd_off = pos
-    val_pos = ifd_off + 2 + 12 * len(ent) + 4
-    ifd, tail = b"", b""
-    for tag, typ, vals in ent:
-        if typ == 2:
-            data = vals.encode("latin-1") + b"\0"
-            cnt = len(data)
-        else:
-            data = struct.pack("<" + fmt[typ] * len(vals), *vals)
-            cnt = len(vals)
-        e = struct.pack("<HHI", tag, typ, cnt)
-        if len(data) <= 4:
-            e += data.ljust(4, b"\0")
-        else:
-            e += struct.pack("<I", val_pos + len(tail))
-            tail += data + (b"\0" if len(data) & 1 else b"")
-        ifd += e
-    pieces = [b"II" + struct.pack("<HI", 42, ifd_off)]
-    for e in enc:
-        pieces.append(e if not len(e) & 1 else e + b"\0")
-    pieces.append(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)
-    write_pieces(path, pieces)
+    # the strips go to the file as they come off the pool, in order (the offsets of a strip are known once its predecessors' sizes
+    # are): the write loop runs under the encoding of the strips behind it instead of after all of it; the IFD follows the data, and
+    # the header's pointer to it is patched in last
+    offs, sizes, pos = [], [], 8
+    ok = False
+    try:
+        with open(path, "wb") as f:
+            f.write(b"II" + struct.pack("<HI", 42, 0))
+            for e in hostpool.pool().map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips):
+                offs.append(pos)
+                sizes.append(len(e))
+                f.write(e)
+                if len(e) & 1:
+                    f.write(b"\0")
+                pos += len(e) + (len(e) & 1)
+                if pos >= (1 << 32) - (1 << 20):
+                    raise ValueError("output exceeds the 4 GiB of a classic TIFF")
+            ent = [(256, 4, (w,)), (257, 4, (h,)), (258, 3, (8, 8, 8)), (259, 3, (5,)), (262, 3, (2,)), (273, 4, tuple(offs)),
+                   (277, 3, (3,)), (278, 4, (rows_per_strip,)), (279, 4, tuple(sizes)), (284, 3, (1,)), (339, 3, (1, 1, 1))]
+            for tag, val in georef.tags.items():
+                if tag == TAG_GEOKEYS:
+                    ent.append((tag, 3, tuple(int(v) for v in val)))
+                elif tag == TAG_GEOASCII:
+                    ent.append((tag, 2, val if isinstance(val, str) else str(val)))
+                else:
+                    ent.append((tag, 12, tuple(float(v) for v in val)))
+            ent.sort(key=lambda e: e[0])
+            fmt = {3: "H", 4: "I", 12: "d"}
+            ifd_off = pos
+            val_pos = ifd_off + 2 + 12 * len(ent) + 4
+            ifd, tail = b"", b""
+            for tag, typ, vals in ent:
+                if typ == 2:
+                    data = vals.encode("latin-1") + b"\0"
+                    cnt = len(data)
+                else:
+                    data = struct.pack("<" + fmt[typ] * len(vals), *vals)
+                    cnt = len(vals)
+                e = struct.pack("<HHI", tag, typ, cnt)
+                if len(data) <= 4:
+                    e += data.ljust(4, b"\0")
+                else:
+                    e += struct.pack("<I", val_pos + len(tail))
+                    tail += data + (b"\0" if len(data) & 1 else b"")
+                ifd += e
+            f.write(struct.pack("<H", len(ent)) + ifd + struct.pack("<I", 0) + tail)
+            f.seek(4)
+            f.write(struct.pack("<I", ifd_off))
+        ok = True
+    finally:
+        if not ok:
+            try:
+                os.unlink(path)            # no half-written GeoTIFF stays behind a failed writer
+            except OSError:
+                pass
     if remember:
         _remember_written(path, rgb, georef)
