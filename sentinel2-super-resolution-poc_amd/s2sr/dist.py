@@ -282,10 +282,11 @@ def enhance_distributed(backend, img: np.ndarray, tile: int = 256, pad: int = 10
     that post-processes it and writes the GeoTIFF): 1/world of an all-gather's traffic per link; the other ranks return
     None.  dst=None: all-gather -- every rank gets the mosaic (world x the receive traffic and a full mosaic
     per rank, only for callers that really consume it everywhere).
-    enhance_crops: post-process parameters (native.pp_wow() / pp_farm()) or None.  The mosaic is BGR like
-    everything `enhance` handles (wow_sr.py:85,94); the post-process runs on its RGB view, on the
-    consuming rank(s), over the WHOLE mosaic after the stitch -- CLAHE's 8x8 grid is image-global
-    (wow_sr.py:191-192), so it cannot run per window.
+    enhance_crops: post-process parameters (native.pp_wow() / pp_farm()) or None -- the reference's default request carries it
+    (main.py:204,227).  The mosaic is BGR like everything `enhance` handles (wow_sr.py:85,94) and stays BGR: the kernels take the
+    channel order as a flag.  CLAHE's 8x8 grid is image-global (wow_sr.py:191-192), so the post-process cannot run per window: on
+    the consuming rank(s) every stitched band is counted into the histograms as it completes (communication stream, under the
+    remaining compute), the LUTs are built behind the last band, and the mosaic is finished and copied out in row bands.
     stats: optional dict that receives the chunk plan and band count of this call."""
     world, rank = dist.get_world_size(), dist.get_rank()
     H, W, _ = img.shape
