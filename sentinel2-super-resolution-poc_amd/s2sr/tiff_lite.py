@@ -127,8 +127,33 @@ def read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
         raise TiffError(f"{path}: malformed TIFF ({type(e).__name__}: {e})") from e
 
 
+def _read_file(path):
+    """The file's bytes.  Large files (an SR output is 40 - 60 MB) are read in 2-MB slices from the host pool into one buffer: the
+    copy out of the page cache is what `read_bytes` spends its 8 - 9 ms in, on one thread."""
+    size = os.stat(path).st_size
+    if size < (8 << 20) or not hasattr(os, "preadv"):
+        return Path(path).read_bytes()
+    from . import hostpool
+    buf = bytearray(size)
+    mv = memoryview(buf)
+    step = 2 << 20
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        def get(a):
+            b = min(size, a + step)
+            while a < b:
+                n = os.preadv(fd, [mv[a:b]], a)
+                if n <= 0:
+                    raise TiffError(f"{path}: the file shrank while it was read")
+                a += n
+        list(hostpool.pool().map(get, range(0, size, step)))
+    finally:
+        os.close(fd)
+    return buf
+
+
 def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
-    raw = Path(path).read_bytes()
+    raw = _read_file(path)
     buf = memoryview(raw)
     if len(raw) < 8 or raw[:2] not in (b"II", b"MM"):
         raise TiffError(f"{path}: not a TIFF file")
