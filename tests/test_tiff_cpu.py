@@ -208,6 +208,26 @@ def test_lzw_encoder_roundtrip_and_libtiff_reads_it(tmp_path):
     assert np.array_equal(rio.read_rgb_u8(p)[0], a)
 
 
+def test_large_files_are_read_in_slices(tmp_path):
+    """Files of 8 MB and more are read in 2-MB slices from the host pool (tiff_lite._read_file), their LZW strips decoded straight
+    into the rows of the result: a 1536 x 2048 RGB raster (literal-form and dictionary-form strips mixed) comes back exactly, with its
+    geo tags, and the reader still refuses a file that is cut short."""
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (1536, 2048, 3), dtype=np.uint8)
+    a[700:900] = (np.arange(2048) // 9 % 256).astype(np.uint8)[None, :, None]           # compressible strips in between
+    geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0)})
+    p = tmp_path / "big.tif"
+    rio.write_geotiff_rgb(p, a, geo)
+    assert p.stat().st_size > (8 << 20)
+    back, tags = tiff_lite.read_tiff(p)
+    assert np.array_equal(back, a) and tuple(tags[rio.TAG_PIXEL_SCALE]) == (2.5, 2.5, 0.0)
+    assert np.array_equal(np.asarray(Image.open(p)), a)
+    cut = tmp_path / "cut.tif"
+    cut.write_bytes(p.read_bytes()[:9 << 20])
+    with pytest.raises(tiff_lite.TiffError):
+        tiff_lite.read_tiff(cut)
+
+
 def test_png_encoder_bands_form_one_stream():
     """Parallel PNG encoder: bands deflated independently and stitched with sync flushes + a combined
     Adler-32 must decode (PIL / zlib) to the input, for RGB and RGBA, with and without threads."""
