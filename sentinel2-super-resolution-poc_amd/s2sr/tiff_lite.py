@@ -134,7 +134,7 @@ def _read_file(path):
     if size < (8 << 20) or not hasattr(os, "preadv"):
         return Path(path).read_bytes()
     from . import hostpool
-    buf = bytearray(size)
+    buf = np.empty(size, np.uint8)            # (not a bytearray: that would be zero-filled, on this thread, first)
     mv = memoryview(buf)
     step = 2 << 20
     fd = os.open(path, os.O_RDONLY)
@@ -149,7 +149,7 @@ def _read_file(path):
         list(hostpool.pool().map(get, range(0, size, step)))
     finally:
         os.close(fd)
-    return buf
+    return mv
 
 
 def _read_tiff(path) -> Tuple[np.ndarray, Dict[int, tuple]]:
