@@ -411,6 +411,14 @@ def test_enhance_job_equals_the_separate_steps(monkeypatch, tmp_path):
             want = e._engine.postprocess_u8(sr_rgb, prm)
             got = e.enhance_job(rgb, prm)
             assert np.array_equal(got, want), (H, W, prm.blur_sigma)
+    # the same chunked job into a PAGEABLE result (S2SR_PINNED_OUT=0 / a pool at its cap): the finishing bands travel through the
+    # library's pinned staging slices instead of one DMA each -- same bytes
+    native.pinned_pool.on = False
+    try:
+        paged = e.enhance_job(rgb, native.pp_farm())
+    finally:
+        native.pinned_pool.on = True
+    assert np.array_equal(paged, got)
     geo = rio.GeoRef({rio.TAG_PIXEL_SCALE: (2.5, 2.5, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 5e5, 4e6, 0.0)})
     rio.write_outputs(got, tmp_path / "o.png", tmp_path / "o.tif", geo)
     back, g = rio.read_rgb_u8(tmp_path / "o.tif")
