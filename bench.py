@@ -627,6 +627,8 @@ def main():
             pk = PEAK * clocks["sclk_mhz"] / 2400.0
             line["roofline"]["held_clock"] = dict(clocks, peak_at_clock=round(pk, 1),
                                                   frac_at_clock=round(line["roofline"]["achieved"] / pk, 4))
+            if clocks.get("power_w"):   # the step sits at the socket cap whatever the schedule (profiles/r05_two_streams.txt): energy is the budget
+                line["roofline"]["held_clock"]["joules_per_tile"] = round(clocks["power_w"] * dt / (a.steps * B), 3)
 
     aoi_n = int(os.environ.get("S2SR_BENCH_AOI", "4096"))
 
