@@ -243,8 +243,7 @@ def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 1
 
             def write_3857():            # next to the pyramid, not in front of it: its strips fill the CPUs the device calls leave idle
                 try:
-                    rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", np.ascontiguousarray(rgba[..., :3]),
-                                          _mercator_tags(plan.placement))
+                    rio.write_geotiff_rgb(input_path.parent / f"{input_path.stem}_3857.tif", rgba, _mercator_tags(plan.placement))   # alpha dropped per strip
                 except BaseException as e:      # noqa: BLE001 -- surfaced below: a failed writer fails the call
                     err.append(e)
             side = threading.Thread(target=write_3857)
@@ -256,7 +255,9 @@ def process_raster_to_tiles(input_path: Path, tiles_dir: Path, min_zoom: int = 1
             _cut_pyramid(np.ascontiguousarray(rgba), place, tiles_dir, min_zoom, max_zoom, on_device=side is not None)
         finally:
             if side is not None:
+                t5 = time.perf_counter()
                 side.join()
+                LAST_STATS["wait_for_3857_tif"] = time.perf_counter() - t5      # what the warped raster's file still needs behind the pyramid
     if err:
         raise err[0]
     LAST_STATS["pyramid"] = time.perf_counter() - t4

@@ -313,10 +313,18 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
 
     from . import native
 
-    rgb = np.ascontiguousarray(rgb, np.uint8)
+    rgb = np.asarray(rgb)
+    if rgb.ndim != 3 or rgb.shape[2] not in (3, 4) or (rgb.shape[2] == 4 and remember):
+        raise ValueError(f"expected HxWx3 (or HxWx4, whose alpha is dropped), got {rgb.shape}")
     h, w, c = rgb.shape
-    if c != 3:
-        raise ValueError(f"expected HxWx3, got {rgb.shape}")
+    if c == 3:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        strip_bytes = lambda s: rgb[s[0]:s[1]].reshape(-1)      # noqa: E731
+    else:
+        # an RGBA raster in hand (the tiler's warp result): its alpha is dropped strip by strip inside the pool -- a whole-image
+        # rgba[..., :3] copy in front of the encoder is one thread moving a gigabyte for a 16k x 16k raster (tools/job_big_probe.py)
+        rgb = rgb if rgb.dtype == np.uint8 else rgb.astype(np.uint8)
+        strip_bytes = lambda s: np.ascontiguousarray(rgb[s[0]:s[1], :, :3]).reshape(-1)      # noqa: E731
     strips = [(y, min(h, y + rows_per_strip)) for y in range(0, h, rows_per_strip)]
     from . import hostpool
     # the strips go to the file as they come off the pool, in order (the offsets of a strip are known once its predecessors' sizes
@@ -327,7 +335,7 @@ def write_geotiff_rgb(path: Path, rgb: np.ndarray, georef: GeoRef, rows_per_stri
     try:
         with open(path, "wb") as f:
             f.write(b"II" + struct.pack("<HI", 42, 0))
-            for e in hostpool.pool().map(lambda s: native.tiff_lzw_encode(rgb[s[0]:s[1]].reshape(-1)), strips):
+            for e in hostpool.pool().map(lambda s: native.tiff_lzw_encode(strip_bytes(s)), strips):
                 offs.append(pos)
                 sizes.append(len(e))
                 f.write(e)

@@ -206,6 +206,15 @@ def test_lzw_encoder_roundtrip_and_libtiff_reads_it(tmp_path):
     assert p.stat().st_size < 1.14 * 130 * 1500 + 20000
     assert np.array_equal(np.asarray(Image.open(p)), a)
     assert np.array_equal(rio.read_rgb_u8(p)[0], a)
+    # an RGBA raster (the tiler's warp result next to its <stem>_3857.tif): alpha dropped strip by strip, the same file as from the RGB copy
+    rgba = np.dstack([a, rng.integers(0, 256, a.shape[:2], dtype=np.uint8)])
+    rio.write_geotiff_rgb(tmp_path / "from_rgba.tif", rgba, geo)
+    assert (tmp_path / "from_rgba.tif").read_bytes() == p.read_bytes()
+    with pytest.raises(ValueError):
+        rio.write_geotiff_rgb(tmp_path / "bad.tif", rgba[..., :2], geo)
+    with pytest.raises(ValueError):
+        rio.write_geotiff_rgb(tmp_path / "bad.tif", rgba, geo, remember=True)
+    assert not (tmp_path / "bad.tif").exists()
 
 
 def test_large_files_are_read_in_slices(tmp_path):

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Probe: a whole /api/wow job on a LARGE AOI (side x side GeoTIFF -> 4*side GeoTIFF + PNG on disk, then the tile pyramid), stage by
+stage: where does the wall time of configs[2]'s image go once it comes from and goes to files?
+
+    python3 tools/job_big_probe.py --side 4096 --zoom-max 16
+"""
+import argparse
+import contextlib
+import io
+import os
+import shutil
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "sentinel2-super-resolution-poc_amd"))
+sys.path.insert(0, str(REPO))
+import torch  # noqa: E402
+
+from s2sr import native  # noqa: E402
+from s2sr import rasterio_lite as rio  # noqa: E402
+from s2sr.weights import synthetic_state_dict  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--side", type=int, default=4096)
+ap.add_argument("--zoom-max", type=int, default=16)
+ap.add_argument("--runs", type=int, default=3)
+a = ap.parse_args()
+
+tmp = Path(tempfile.mkdtemp(prefix="s2sr_bigjob_"))
+try:
+    os.environ["S2SR_MODEL_DIR"] = str(tmp / "models")
+    (tmp / "models").mkdir()
+    torch.save({"params_ema": {k: torch.from_numpy(v) for k, v in synthetic_state_dict(23, seed=0).items()}}, tmp / "models" / "realesrgan_x4.pth")
+    side = a.side
+    yy, xx = np.mgrid[0:side, 0:side].astype(np.float32)
+    rng = np.random.default_rng(0)
+    rgb = np.stack([110 + 70 * np.sin(xx / 23.0 + c) * np.cos(yy / 17.0) + rng.integers(-12, 13, (side, side)) for c in range(3)], -1)
+    georef = rio.GeoRef({rio.TAG_PIXEL_SCALE: (10.0, 10.0, 0.0), rio.TAG_TIEPOINT: (0.0, 0.0, 0.0, 600000.0, 5100000.0, 0.0),
+                         rio.TAG_GEOKEYS: (1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, 32633)})
+    img8 = np.clip(rgb, 0, 255).astype(np.uint8)
+    del rgb, xx, yy
+    rio.write_geotiff_rgb(tmp / "aoi.tif", img8, georef)
+    print(f"input {side}x{side}: {(tmp / 'aoi.tif').stat().st_size / 1e6:.1f} MB on disk", flush=True)
+
+    import app.tiling as tiling
+    from app.cnn_super_resolution import RealESRGAN
+    from app.wow_sr import process_wow_sr
+
+    for i in range(a.runs):
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            res = process_wow_sr(tmp / "aoi.tif", tmp / f"run{i % 2}")
+            t_job = time.perf_counter() - t0
+        print(f"job {i}: {t_job * 1e3:8.1f} ms", flush=True)
+
+    # the same stages by hand
+    t0 = time.perf_counter()
+    img, gr = rio.read_rgb_u8(tmp / "aoi.tif")
+    t_read = time.perf_counter() - t0
+    es = RealESRGAN(model_name="realesrgan_x4", tile_size=256)
+    t0 = time.perf_counter()
+    out = es.enhance_job(img, native.pp_wow())
+    t_sr = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = es.enhance_job(img, native.pp_wow())
+    t_sr2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rio.write_geotiff_rgb(tmp / "only.tif", out, gr.scaled(4))
+    t_tif = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rio.write_png(tmp / "only.png", out)
+    t_png = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rio.write_outputs(out, tmp / "both.png", tmp / "both.tif", gr.scaled(4))
+    t_both = time.perf_counter() - t0
+    print(f"stages: read {t_read * 1e3:.1f} ms  enhance_job {t_sr * 1e3:.1f} / {t_sr2 * 1e3:.1f} ms  GeoTIFF alone {t_tif * 1e3:.1f} ms "
+          f"({(tmp / 'only.tif').stat().st_size / 1e6:.0f} MB)  PNG alone {t_png * 1e3:.1f} ms ({(tmp / 'only.png').stat().st_size / 1e6:.0f} MB)  "
+          f"both side by side {t_both * 1e3:.1f} ms", flush=True)
+    del out, img
+
+    sr_tif = Path(res["outputs"]["sr_tif"])
+    for zmax in (12, a.zoom_max, a.zoom_max, a.zoom_max):
+        shutil.rmtree(tmp / f"tiles{zmax}", ignore_errors=True)
+        os.sync()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            tiling.process_raster_to_tiles(sr_tif, tmp / f"tiles{zmax}", 10, zmax)
+        t_tiles = time.perf_counter() - t0
+        n = sum(1 for _ in (tmp / f"tiles{zmax}").glob("*/*/*.png"))
+        print(f"pyramid z10..{zmax}: {t_tiles * 1e3:8.1f} ms, {n} tiles; stages {{{', '.join(f'{k}: {v * 1e3:.1f}' for k, v in tiling.LAST_STATS.items())}}}", flush=True)
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
