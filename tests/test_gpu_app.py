@@ -390,6 +390,33 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert ao["enhance_crops"]["value"] > 0 and ao["enhance_crops"]["seconds"] > 0
 
 
+def test_job_result_beyond_2_gib(monkeypatch, tmp_path):
+    """Maximum sizes: a 2816 x 16384 AOI (704 windows of the 256 / 10 plan) gives an 11264 x 65536 x 3 result of 2.21 GB -- byte offsets
+    past 2^31 in the stitch, the band-wise swaps, histograms, apply + sharpen and the copies out.  Checked through what does not depend
+    on the size: (1) windows see only their own 276 x 276 pixels, so the job of the bottom-right 1792 x 4096 crop (small offsets
+    everywhere) gives the same bytes away from the crop's own top / left windows; (2) the band-wise post-process of the job equals
+    the whole-image launch of s2sr_postprocess_u8 on the plain job's result."""
+    import app.cnn_super_resolution as m
+    from s2sr import native
+    _patch_weights(monkeypatch, tmp_path, {"realesrgan_anime": 6})
+    e = m.RealESRGAN(model_name="realesrgan_anime", tile_size=256)
+    H, W, y0, x0 = 2816, 16384, 1024, 12288
+    rng = np.random.default_rng(77)
+    rgb = rng.integers(0, 256, (H // 8, W // 8, 3), dtype=np.uint8).repeat(8, 0).repeat(8, 1)     # blocky: statistics of an image, cheap to draw
+    rgb += rng.integers(0, 8, (H, W, 3), dtype=np.uint8)
+    rgb[..., 1] = np.maximum(rgb[..., 1], 90)
+    big = e.enhance_job(rgb, None)
+    assert big.shape == (4 * H, 4 * W, 3) and big.nbytes > 2 ** 31
+    small = e.enhance_job(np.ascontiguousarray(rgb[y0:, x0:]), None)
+    assert np.array_equal(big[4 * (y0 + 256):, 4 * (x0 + 256):], small[4 * 256:, 4 * 256:])
+    assert big[-1, -1].tolist() == small[-1, -1].tolist() and int(big[4 * (y0 + 256):].max()) > 0
+    del small
+    prm = native.pp_wow()
+    got = e.enhance_job(rgb, prm)
+    want = e._engine.postprocess_u8(big, prm)
+    assert np.array_equal(got, want)
+
+
 def test_enhance_job_equals_the_separate_steps(monkeypatch, tmp_path):
     """s2sr_enhance_job_u8 (RealESRGAN.enhance_job: RGB in, RGB2BGR, the net, BGR2RGB, the post-process, RGB out -- one upload, one
     download) gives the bytes of the reference's own sequence (wow_sr.py:85-110: cvtColor, enhance, cvtColor, _enhance_for_crops)
