@@ -91,7 +91,13 @@ try:
         with contextlib.redirect_stdout(io.StringIO()):
             tiling.process_raster_to_tiles(sr_tif, tmp / f"tiles{zmax}", 10, zmax)
         t_tiles = time.perf_counter() - t0
-        n = sum(1 for _ in (tmp / f"tiles{zmax}").glob("*/*/*.png"))
+        files = sorted((tmp / f"tiles{zmax}").glob("*/*/*.png"))
+        n = len(files)
+        from PIL import Image
+        for f in files[:: max(1, n // 40)]:                    # a sample of the level files decodes to 256 x 256 RGBA
+            im = Image.open(f)
+            im.load()
+            assert im.size == (256, 256) and im.mode == "RGBA", f
         print(f"pyramid z10..{zmax}: {t_tiles * 1e3:8.1f} ms, {n} tiles; stages {{{', '.join(f'{k}: {v * 1e3:.1f}' for k, v in tiling.LAST_STATS.items())}}}", flush=True)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
