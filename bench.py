@@ -300,9 +300,10 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
     out = {"note": "one workgroup per CU, 8 waves, random fp16 operands in (-1, 1); stages of 288 MFMAs / 216 ds_read_b128 / 48 KiB LDS-DMA per "
                    "workgroup as in conv_trunk_f16 conv1-4 (28 stages per workgroup = the MFMA work of one launch of 16 images); no epilogue, no stores",
            "stages_per_launch": 448}
-    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (5, "lds_dma_fed_kernel_mix"), (3, "lds_dma_fed_half_bytes"), (4, "lds_dma_fed_from_cache")):
+    for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (5, "lds_dma_fed_kernel_mix"), (6, "lds_dma_fed_conv5_mix"), (3, "lds_dma_fed_half_bytes"),
+                      (4, "lds_dma_fed_from_cache")):
         probe = eng.mfma_ceiling(mode, 448, 8)                         # settles the clock and sizes the timed run
-        launches = int(max(16, min(4000, (0.5e6 if mode in (0, 1, 2, 5) else 0.3e6) / max(probe["us_per_launch"], 1.0))))   # ~3 s for the six loops
+        launches = int(max(16, min(4000, (0.5e6 if mode in (0, 1, 2, 5) else 0.3e6) / max(probe["us_per_launch"], 1.0))))   # ~3.5 s for the seven loops
         sampler = ClockSampler(device_index)
         sampler.start()
         r = eng.mfma_ceiling(mode, 448, launches)
@@ -315,6 +316,10 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
             leg["what"] = ("the kernel's own traffic mix: 36 of the 48 KiB per stage streamed from HBM (slab planes), 12 KiB from a cached source (the weights "
                            "every workgroup re-fetches), 8 KiB stored per stage (the launch's output): per 16-image launch 264 MB read + 59 MB written, against "
                            "243 + 67 MB in the counters of conv1-4; lds_dma_GB_per_s counts all 48 KiB")
+        if mode == 6:
+            leg["what"] = ("conv5's mix (64 output channels: 576 MFMAs per 36-KiB slab plane + 18 KiB of weights, 0.44 LDS reads per MFMA, 192 KiB of residual read "
+                           "and 192 KiB stored per patch) scaled to the 48-KiB stage: 384 MFMAs, 32 KiB streamed from HBM, 16 KiB from the cached source, 12 KiB "
+                           "stored per stage -- 117 B of HBM traffic per MFMA against 114 algorithmic (99 in the counters of conv5); no epilogue arithmetic")
         if mode == 3:
             leg["what"] = "lds_dma_fed with 24 KiB of LDS-DMA per 288 MFMAs: what a schedule that moved half the bytes per FLOP would be fed at"
         if mode == 4:
@@ -832,6 +837,11 @@ def main():
                 line["roofline"]["frac_of_fed_ceiling_kernel_mix"] = round(line["roofline"]["achieved"] / mix, 4)
                 line["roofline"]["fed_ceiling_kernel_mix_TFLOP_per_s"] = mix
                 line["roofline"]["bare_loop_TFLOP_per_s"] = sec["mfma_ceiling"]["bare"]["TFLOP_per_s"]
+                c5 = line["roofline"]["families"].get("rdb_conv5", {}).get("TFLOP_per_s")
+                mix5 = sec["mfma_ceiling"]["lds_dma_fed_conv5_mix"]["TFLOP_per_s"]
+                if c5 and mix5:      # conv5 (the other 40 % of the RDB time) against a loop with ITS bytes per FLOP
+                    line["roofline"]["conv5_frac_of_fed_ceiling"] = round(c5 / mix5, 4)
+                    line["roofline"]["conv5_fed_ceiling_TFLOP_per_s"] = mix5
         except Exception as e:      # noqa: BLE001
             sec["mfma_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:

@@ -289,7 +289,7 @@ hipError_t launch_pp_band_sharpen(int H, int W, const s2sr_pp_params& prm, int b
 // measured MFMA ceilings (ceiling.hip): bare / LDS-fed / LDS-DMA-fed fp16 32x32x16 loops at conv_trunk_f16's operand traffic
 hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, char* d_store,
                                size_t store_bytes, hipStream_t st);
-double mfma_ceiling_flop_per_launch(int grid, int stages);
+double mfma_ceiling_flop_per_launch(int mode, int grid, int stages);
 double mfma_ceiling_dma_bytes_per_launch(int mode, int grid, int stages);
 
 }  // namespace s2sr

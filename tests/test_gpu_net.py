@@ -1140,3 +1140,24 @@ def test_shared_card_falls_back_to_smaller_groups_and_fails_loudly_when_nothing_
         torch.cuda.empty_cache()
     assert np.array_equal(e.forward_batch_u8(tiles), want)       # the same handle, once there is room again
     e.close()
+
+
+def test_mfma_ceiling_modes_run():
+    """The diagnostic loops behind bench.py's secondary.mfma_ceiling (csrc/ceiling.hip): every mode launches, drains and reports its
+    work -- 288 MFMAs per workgroup and stage (384 in conv5's mix), 48 KiB of LDS-DMA per stage in the fed modes (24 in mode 3); an
+    unknown mode is refused."""
+    e = native.Engine(num_block=1)
+    try:
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        for mode in range(7):
+            r = e.mfma_ceiling(mode, 6, 2)
+            assert r["ms"] > 0 and r["TFLOP_per_s"] > 1.0, (mode, r)
+            flop = r["TFLOP_per_s"] * 1e12 * r["ms"] * 1e-3 / 2
+            assert abs(flop - ncu * 6 * (384 if mode == 6 else 288) * 32768.0) < 1e-6 * flop, (mode, flop)
+            dma = r["dma_GB_per_s"] * 1e9 * r["ms"] * 1e-3 / 2
+            want = 0 if mode < 2 else ncu * 6 * (24 if mode == 3 else 48) * 1024
+            assert abs(dma - want) <= 1e-6 * max(want, 1), (mode, dma)
+        with pytest.raises(native.S2srError):
+            e.mfma_ceiling(7, 6, 2)
+    finally:
+        e.close()
