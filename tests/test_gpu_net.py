@@ -1027,6 +1027,42 @@ def test_dist_aoi_chunked_equals_enhance():
         dist.destroy_process_group()
 
 
+def test_dist_aoi_result_beyond_2_gib():
+    """Maximum sizes on the multi-GPU orchestration: a 2816 x 16384 AOI (704 windows, an 11264 x 65536 x 3 result of 2.21 GB) through
+    enhance_distributed with one rank over RCCL -- gather views, band stitch, band-wise post-process and the copies out at byte offsets
+    past 2^31 -- gives the bytes of s2sr_enhance_u8 / s2sr_enhance_job_u8 (whose own check at this size is
+    tests/test_gpu_app.py test_job_result_beyond_2_gib)."""
+    import os
+    import torch.distributed as dist
+    from s2sr.dist import NativeBackend, enhance_distributed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        e = engine(6, native.PREC_F16_HP)
+        be = NativeBackend(e, 0)
+        rng = np.random.default_rng(78)
+        H, W = 2816, 16384
+        img = rng.integers(0, 256, (H // 8, W // 8, 3), dtype=np.uint8).repeat(8, 0).repeat(8, 1)
+        img += rng.integers(0, 8, (H, W, 3), dtype=np.uint8)
+        img[..., 1] = np.maximum(img[..., 1], 90)
+        side = torch.cuda.Stream()
+        exp = e.enhance_u8(img, tile=256, pad=10)
+        assert exp.nbytes > 2 ** 31
+        st = {}
+        with torch.cuda.stream(side):
+            got = enhance_distributed(be, img, 256, 10, dst=0, stats=st)
+        assert np.array_equal(got, exp) and st["windows"] == 704 and st["bands"] >= 2, st
+        del got, exp
+        want = e.enhance_job_u8(np.ascontiguousarray(img[:, :, ::-1]), native.pp_wow(), tile=256, pad=10)[:, :, ::-1]
+        with torch.cuda.stream(side):
+            got = enhance_distributed(be, img, 256, 10, dst=0, enhance_crops=native.pp_wow())
+        assert np.array_equal(got, want)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_aoi_chunks_share_one_workspace():
     """ADVICE r03 (medium x2): (a) an AOI whose window count is no multiple of the mosaic (1280x1280 at 256/10: 25 windows) used
     to re-pick the mosaic per chunk -- another image height for the short last chunk, so the multi-GB workspace was reallocated
