@@ -228,6 +228,22 @@ def test_errors_are_loud():
     with pytest.raises(native.S2srError):
         e.load_blob(np.zeros(10, np.float32))                      # wrong blob size
     e.close()
+    # empty and degenerate inputs are refused at the boundary (the reference's enhance() would fail inside cv2 / torch on them), and
+    # the handle keeps working afterwards
+    e = engine(1)
+    img = np.random.default_rng(3).integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    want = e.enhance_u8(img)
+    for bad in (np.zeros((0, 5, 3), np.uint8), np.zeros((5, 0, 3), np.uint8)):
+        with pytest.raises(native.S2srError):
+            e.enhance_u8(bad)
+        with pytest.raises(native.S2srError):
+            e.enhance_job_u8(bad, native.pp_wow())
+    with pytest.raises(native.S2srError):
+        e.enhance_u8(img, tile=0)
+    with pytest.raises(native.S2srError):
+        e.enhance_u8(img, pad=-1)
+    assert e.forward_batch_u8(np.zeros((0, 8, 8, 3), np.uint8)).shape == (0, 32, 32, 3)      # an empty batch is an empty result
+    assert np.array_equal(e.enhance_u8(img), want)
 
 
 def test_cut_forward_stitch_equals_enhance():
