@@ -301,9 +301,9 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
                    "workgroup as in conv_trunk_f16 conv1-4 (28 stages per workgroup = the MFMA work of one launch of 16 images); no epilogue, no stores",
            "stages_per_launch": 448}
     for mode, key in ((0, "bare"), (1, "lds_fed"), (2, "lds_dma_fed"), (5, "lds_dma_fed_kernel_mix"), (6, "lds_dma_fed_conv5_mix"), (3, "lds_dma_fed_half_bytes"),
-                      (4, "lds_dma_fed_from_cache")):
+                      (4, "lds_dma_fed_from_cache"), (7, "lds_dma_fed_from_100MB"), (8, "lds_dma_fed_from_200MB")):
         probe = eng.mfma_ceiling(mode, 448, 8)                         # settles the clock and sizes the timed run
-        launches = int(max(16, min(4000, (0.5e6 if mode in (0, 1, 2, 5) else 0.3e6) / max(probe["us_per_launch"], 1.0))))   # ~3.5 s for the seven loops
+        launches = int(max(16, min(4000, (0.5e6 if mode in (0, 1, 2, 5) else 0.3e6) / max(probe["us_per_launch"], 1.0))))   # ~4 s for the nine loops
         sampler = ClockSampler(device_index)
         sampler.start()
         r = eng.mfma_ceiling(mode, 448, launches)
@@ -324,6 +324,9 @@ def mfma_ceiling_leg(eng, device_index: int) -> dict:
             leg["what"] = "lds_dma_fed with 24 KiB of LDS-DMA per 288 MFMAs: what a schedule that moved half the bytes per FLOP would be fed at"
         if mode == 4:
             leg["what"] = "lds_dma_fed (48 KiB) from a 7.5-MB source that stays in L2 / MALL: the LDS fill without the HBM side"
+        if mode in (7, 8):
+            leg["what"] = (f"lds_dma_fed (48 KiB) from a {100 * (mode - 6)}-MB source: past the L2s, inside the 256-MB Infinity Cache -- the dense tensor of a launch "
+                           f"group of {4 * (mode - 6)} images: what a schedule whose working set stayed cache-resident would be fed at")
 
         if clocks:
             leg.update(sclk_mhz=clocks["sclk_mhz"], power_w=clocks["power_w"],

@@ -372,7 +372,8 @@ int  s2sr_debug_bench_conv(s2sr_handle* h, int32_t N, int32_t H, int32_t W, int3
  * MFMAs from a 336-MB buffer (3-deep ring, counted vmcnt, one barrier per stage); 3: as 2 with half the fill (24 KiB); 4: as 2 from
  * an 8-MB source that stays in L2 / MALL (the fill without the HBM side); 5: the kernel's own mix -- 36 KiB streamed from HBM, 12 KiB
  * from the cached source (the weights), 8 KiB stored per stage (its output); 6: conv5's mix -- 384 MFMAs per stage (64 output channels),
- * 0.44 LDS reads per MFMA, 32 KiB streamed, 16 KiB cached, 12 KiB stored.  One workgroup per CU, random fp16 operands;
+ * 0.44 LDS reads per MFMA, 32 KiB streamed, 16 KiB cached, 12 KiB stored; 7 / 8: as 2 from a 100-MB / 200-MB source (past the L2s, inside
+ * the Infinity Cache: the dense tensor of a launch group of 4 / 8 images).  One workgroup per CU, random fp16 operands;
  * `launches` back-to-back launches of `stages` stages per workgroup behind launches / 4 + 1 untimed ones; *ms_total = their
  * time by HIP events, *flop_per_launch / *dma_bytes_per_launch = the work of one (28 stages = one conv1-4 launch of 16 images). */
 int  s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch,

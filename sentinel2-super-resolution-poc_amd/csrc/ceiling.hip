@@ -19,6 +19,8 @@
 //           48-KiB stage: 384 MFMAs per stage, 32 KiB streamed from HBM (21.3 slab + 10.7 residual, taken through the ring as well),
 //           16 KiB from the cached source (12 weights + the halo the neighbours' L2 lines serve), 12 KiB stored: 117 B of HBM traffic
 //           per MFMA against 114 algorithmic (99 in the counters) -- what a loop with conv5's bytes per FLOP and no epilogue sustains
+//   mode 7 / 8  as 2 from a 100-MB / 200-MB source: past the L2s (8 x 4 MB), inside the 256-MB Infinity Cache -- the dense tensor of a launch
+//           group of 4 / 8 images: what a schedule whose working set stayed cache-resident would be fed at
 // Random fp16 operands in (-1, 1) (toggle rates, and with them power, depend on the data).  Two waves per SIMD so that LDS latency
 // hides without hand scheduling: these are ceilings, the occupancy is free to choose.  Diagnostic entry; nothing of the product
 // calls it.
@@ -168,8 +170,8 @@ namespace s2sr {
 // launch error; FLOP of one launch = grid * stages * 8 waves * 36 MFMAs * 32768.
 hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fill, float* d_sink, int grid, int stages, char* d_store,
                                size_t store_bytes, hipStream_t st) {
-    if (mode >= 5 && (!d_store || store_bytes < (1u << 20))) return hipErrorInvalidValue;
-    if (mode < 0 || mode > 6 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
+    if ((mode == 5 || mode == 6) && (!d_store || store_bytes < (1u << 20))) return hipErrorInvalidValue;
+    if (mode < 0 || mode > 8 || grid <= 0 || stages <= 0 || src_bytes < (size_t)STAGE) return hipErrorInvalidValue;
     if (fill) hipLaunchKernelGGL(fill_random_f16, dim3(2048), dim3(256), 0, st, (uint32_t*)d_src, src_bytes / 4);
     uint32_t nchunks = (uint32_t)(src_bytes / STAGE);
     const size_t lds = (size_t)RING * STAGE;
@@ -185,7 +187,9 @@ hipError_t launch_mfma_ceiling(int mode, char* d_src, size_t src_bytes, bool fil
     });
     if (attr_err != hipSuccess) return attr_err;
     if (mode == 4) nchunks = nchunks < 160 ? nchunks : 160;       // 7.5 MB of source: resident in L2 / MALL
-    hipLaunchKernelGGL(kern[mode], dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages, d_store, (uint32_t)(store_bytes >> 10));
+    if (mode == 7) nchunks = nchunks < 2133 ? nchunks : 2133;     // 100 MB: the Infinity Cache, not the L2s
+    if (mode == 8) nchunks = nchunks < 4266 ? nchunks : 4266;     // 200 MB
+    hipLaunchKernelGGL(kern[mode >= 7 ? 2 : mode], dim3(grid), dim3(512), lds, st, d_src, nchunks, d_sink, stages, d_store, (uint32_t)(store_bytes >> 10));
     return hipGetLastError();
 }
 

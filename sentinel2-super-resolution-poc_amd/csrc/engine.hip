@@ -2363,7 +2363,7 @@ int s2sr_debug_conv(s2sr_handle* h, const float* x, int32_t N, int32_t Cin, int3
 // workgroup per CU, timed with an event pair on the handle's stream behind launches / 4 + 1 untimed ones (the clock settles under load)
 int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_t launches, double* flop_per_launch, double* dma_bytes_per_launch,
                             float* ms_total) {
-    if (!h || mode < 0 || mode > 6 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
+    if (!h || mode < 0 || mode > 8 || stages <= 0 || launches <= 0 || !ms_total) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int ncu = 256;

@@ -593,7 +593,7 @@ class Engine:
 
     def mfma_ceiling(self, mode: int, stages: int, launches: int) -> dict:
         """csrc/ceiling.hip: mode 0 bare MFMA loop, 1 + LDS operand reads, 2 + LDS-DMA ring refill (3 half the bytes, 4 from cache, 5 conv1-4's
-        traffic mix, 6 conv5's) -> TFLOP/s over `launches` launches."""
+        traffic mix, 6 conv5's, 7 / 8 from a 100-MB / 200-MB source inside the Infinity Cache) -> TFLOP/s over `launches` launches."""
         fl, by, ms = C.c_double(0), C.c_double(0), C.c_float(0)
         self._check(self._lib.s2sr_debug_mfma_ceiling(self._h, mode, stages, launches, C.byref(fl), C.byref(by), C.byref(ms)),
                     "s2sr_debug_mfma_ceiling")

@@ -1201,7 +1201,7 @@ def test_mfma_ceiling_modes_run():
     e = native.Engine(num_block=1)
     try:
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
-        for mode in range(7):
+        for mode in range(9):
             r = e.mfma_ceiling(mode, 6, 2)
             assert r["ms"] > 0 and r["TFLOP_per_s"] > 1.0, (mode, r)
             flop = r["TFLOP_per_s"] * 1e12 * r["ms"] * 1e-3 / 2
@@ -1210,6 +1210,6 @@ def test_mfma_ceiling_modes_run():
             want = 0 if mode < 2 else ncu * 6 * (24 if mode == 3 else 48) * 1024
             assert abs(dma - want) <= 1e-6 * max(want, 1), (mode, dma)
         with pytest.raises(native.S2srError):
-            e.mfma_ceiling(7, 6, 2)
+            e.mfma_ceiling(9, 6, 2)
     finally:
         e.close()
