@@ -847,6 +847,20 @@ def main():
                     line["roofline"]["conv5_fed_ceiling_TFLOP_per_s"] = mix5
         except Exception as e:      # noqa: BLE001
             sec["mfma_ceiling"] = {"error": f"{type(e).__name__}: {e}"}
+        try:      # the prototype of the schedule those ceilings point to (csrc/persist.hip, profiles/r05_persistent_loop.txt): ~0.6 s
+            ncu = torch.cuda.get_device_properties(local).multi_processor_count
+            eng.rdb_persistent(1, ncu, 2, 23, 8)
+            sampler = ClockSampler(local)
+            sampler.start()
+            r = eng.rdb_persistent(1, ncu, 2, 23, 100)
+            clocks = sampler.stop() or {}
+            sec["persistent_loop"] = {"TFLOP_per_s": round(r["TFLOP_per_s"], 1), "timeouts": r["timeouts"], "seconds": round(r["ms"] * 1e-3, 3),
+                                      "working_set_MB": r["working_set_MB"], "sclk_mhz": clocks.get("sclk_mhz"), "power_w": clocks.get("power_w"),
+                                      "what": "diagnostic prototype, not the product: an RDB-shaped loop (per patch 28 stages of 288 MFMAs + 12 of 576, 48 KiB of LDS-DMA "
+                                              "per stage, the layers' planes stored) whose workgroups stay across layers -- 2 patches per CU, planes handed to the "
+                                              "neighbours through per-patch counters, device-scope loads and written-through stores; 23 RDBs per launch, 100 launches"}
+        except Exception as e:      # noqa: BLE001
+            sec["persistent_loop"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line["secondary"] = sec
     if rank == 0:

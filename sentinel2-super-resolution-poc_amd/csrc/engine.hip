@@ -2392,6 +2392,56 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
     return S2SR_OK;
 }
 
+// diagnostic prototype (persist.hip): `launches` launches of the RDB-shaped loop whose workgroups stay across layers, `grid` workgroups (<= one per
+// CU: they must all be resident) of `P` patches each, `rdbs` RDBs per launch; flags in uncached device memory, zeroed in front of every launch
+int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t coherent, int32_t grid, int32_t P, int32_t rdbs, int32_t launches, double* flop_per_launch,
+                              float* ms_total, int32_t* timeouts) {
+    if (!h || grid < 2 || P < 2 || P > 4 || rdbs < 1 || rdbs > 4000 || launches < 1 || !ms_total) return S2SR_E_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+    if (grid > ncu) return fail(h, S2SR_E_INVALID, "more workgroups than CUs: they would not all be resident");
+    const size_t wts_bytes = (size_t)8 << 20, ws_bytes = rdb_persistent_ws_bytes(grid, P), sink_bytes = (size_t)grid * 512 * 4;
+    int rc = ensure_scratch(h, 2, wts_bytes);
+    if (rc) return rc;
+    if ((rc = ensure_scratch(h, 3, sink_bytes + 256))) return rc;
+    if ((rc = ensure_scratch(h, 4, ws_bytes))) return rc;
+    struct Uncached {
+        void* p = nullptr;
+        ~Uncached() { if (p) (void)hipFree(p); }
+    } fl;
+    const size_t flag_bytes = ((size_t)grid * P + 1) * 4;
+    HIPCHK(h, hipExtMallocWithFlags(&fl.p, flag_bytes, hipDeviceMallocUncached));
+    uint32_t* d_timeouts = (uint32_t*)((char*)h->d_scratch[3] + sink_bytes);
+    hipStream_t st = h->stream;
+    // operand data: the ceiling loops' generator fills the weights buffer and the working set (toggle rates as there)
+    HIPCHK(h, launch_mfma_ceiling(0, (char*)h->d_scratch[2], wts_bytes, true, (float*)h->d_scratch[3], 1, 1, nullptr, 0, st));
+    HIPCHK(h, launch_mfma_ceiling(0, (char*)h->d_scratch[4], ws_bytes, true, (float*)h->d_scratch[3], 1, 1, nullptr, 0, st));
+    HIPCHK(h, hipMemsetAsync(d_timeouts, 0, 4, st));
+    hipEvent_t e0 = get_event(h), e1 = get_event(h);
+    auto one = [&]() -> int {
+        HIPCHK(h, hipMemsetAsync(fl.p, 0, flag_bytes, st));
+        HIPCHK(h, launch_rdb_persistent(coherent, (const char*)h->d_scratch[2], wts_bytes, (char*)h->d_scratch[4], (uint32_t*)fl.p, (float*)h->d_scratch[3],
+                                        grid, P, rdbs, d_timeouts, st));
+        return S2SR_OK;
+    };
+    for (int i = 0; i < launches / 4 + 1; ++i)
+        if ((rc = one())) return rc;
+    HIPCHK(h, hipEventRecord(e0, st));
+    for (int i = 0; i < launches; ++i)
+        if ((rc = one())) return rc;
+    HIPCHK(h, hipEventRecord(e1, st));
+    uint32_t to = 0;
+    HIPCHK(h, hipMemcpyAsync(&to, d_timeouts, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
+    h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
+    if (flop_per_launch) *flop_per_launch = rdb_persistent_flop_per_launch(grid, P, rdbs);
+    if (timeouts) *timeouts = (int32_t)to;
+    return S2SR_OK;
+}
+
 int s2sr_debug_get_config(s2sr_handle* h, s2sr_debug_config* out) {
     if (!h || !out) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);

@@ -138,6 +138,7 @@ _PROTOS = {
     "s2sr_debug_mfma_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_float)]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
+    "s2sr_debug_rdb_persistent": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -600,6 +601,14 @@ class Engine:
         return {"ms": float(ms.value), "launches": launches, "us_per_launch": float(ms.value) * 1e3 / launches,
                 "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
                 "dma_GB_per_s": by.value * launches / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0}
+
+    def rdb_persistent(self, coherent: bool, grid: int, P: int, rdbs: int, launches: int) -> dict:
+        """csrc/persist.hip (diagnostic prototype): the RDB-shaped loop whose workgroups stay across layers -> TFLOP/s, dependency-wait timeouts."""
+        fl, ms, to = C.c_double(0), C.c_float(0), C.c_int32(0)
+        self._check(self._lib.s2sr_debug_rdb_persistent(self._h, int(bool(coherent)), grid, P, rdbs, launches, C.byref(fl), C.byref(ms), C.byref(to)),
+                    "s2sr_debug_rdb_persistent")
+        return {"ms": float(ms.value), "launches": launches, "timeouts": int(to.value), "working_set_MB": grid * P * 0.5,
+                "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
 
     # -- measurement ------------------------------------------------------------------------
     def set_profiling(self, every: int):

@@ -1213,3 +1213,23 @@ def test_mfma_ceiling_modes_run():
             e.mfma_ceiling(9, 6, 2)
     finally:
         e.close()
+
+
+def test_rdb_persistent_prototype_drains():
+    """The diagnostic prototype behind profiles/r05_persistent_loop.txt (csrc/persist.hip): workgroups that stay across the layers of the RDBs and
+    hand planes over through per-patch counters.  It must drain -- no dependency wait runs into its bound -- with plain and with device-scope
+    loads / written-through stores, on a full and on a partial grid, and report the work of its shape; bad arguments are refused."""
+    e = native.Engine(num_block=1)
+    try:
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        for coherent in (0, 1):
+            for grid, P in ((ncu, 2), (ncu // 2, 3), (8, 4)):
+                r = e.rdb_persistent(coherent, grid, P, 3, 2)
+                assert r["timeouts"] == 0 and r["ms"] > 0, (coherent, grid, P, r)
+                flop = r["TFLOP_per_s"] * 1e12 * r["ms"] * 1e-3 / 2
+                assert abs(flop - grid * P * 3 * (28 * 288 + 12 * 576) * 32768.0) < 1e-6 * flop, (grid, P, flop)
+        for bad in ((0, ncu + 1, 2, 3, 1), (0, ncu, 1, 3, 1), (0, ncu, 5, 3, 1), (0, ncu, 2, 0, 1)):
+            with pytest.raises(native.S2srError):
+                e.rdb_persistent(*bad)
+    finally:
+        e.close()
