@@ -2394,15 +2394,15 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
 
 // diagnostic prototype (persist.hip): `launches` launches of the RDB-shaped loop whose workgroups stay across layers, `grid` workgroups (<= one per
 // CU: they must all be resident) of `P` patches each, `rdbs` RDBs per launch; flags in uncached device memory, zeroed in front of every launch
-int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t coherent, int32_t grid, int32_t P, int32_t rdbs, int32_t launches, double* flop_per_launch,
+int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t variant, int32_t grid, int32_t P, int32_t rdbs, int32_t launches, double* flop_per_launch,
                               float* ms_total, int32_t* timeouts) {
-    if (!h || grid < 2 || P < 2 || P > 4 || rdbs < 1 || rdbs > 4000 || launches < 1 || !ms_total) return S2SR_E_INVALID;
+    if (!h || variant < 0 || variant > 3 || grid < 2 || P < 2 || P > 4 || rdbs < 1 || rdbs > 4000 || launches < 1 || !ms_total) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
     if (grid > ncu) return fail(h, S2SR_E_INVALID, "more workgroups than CUs: they would not all be resident");
-    const size_t wts_bytes = (size_t)8 << 20, ws_bytes = rdb_persistent_ws_bytes(grid, P), sink_bytes = (size_t)grid * 512 * 4;
+    const size_t wts_bytes = (size_t)8 << 20, ws_bytes = rdb_persistent_ws_bytes(variant, grid, P), sink_bytes = (size_t)grid * 512 * 4;
     int rc = ensure_scratch(h, 2, wts_bytes);
     if (rc) return rc;
     if ((rc = ensure_scratch(h, 3, sink_bytes + 256))) return rc;
@@ -2422,7 +2422,7 @@ int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t coherent, int32_t grid, in
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     auto one = [&]() -> int {
         HIPCHK(h, hipMemsetAsync(fl.p, 0, flag_bytes, st));
-        HIPCHK(h, launch_rdb_persistent(coherent, (const char*)h->d_scratch[2], wts_bytes, (char*)h->d_scratch[4], (uint32_t*)fl.p, (float*)h->d_scratch[3],
+        HIPCHK(h, launch_rdb_persistent(variant, (const char*)h->d_scratch[2], wts_bytes, (char*)h->d_scratch[4], (uint32_t*)fl.p, (float*)h->d_scratch[3],
                                         grid, P, rdbs, d_timeouts, st));
         return S2SR_OK;
     };

@@ -34,9 +34,19 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int STAGE = 48 * 1024, RING = 3, PW = 6;        // as ceiling.hip
-constexpr int SLAB = 32 * 1024;
-constexpr int kSlabsPerPatch = 16;                                   // xA 0-3, xB 4-7, x1..x4 8-15
+// Two geometries of the same work (same MFMAs, LDS reads per MFMA and bytes per MFMA):
+//   G0  the trunk kernel's: 48-KiB stages, 3-deep ring (two stages of look-ahead), 6 LDS-DMA pieces and 36 (72) MFMAs per wave and stage,
+//       32-KiB slabs: x 4, x1..x4 2 each;
+//   G1  deeper look-ahead on the same 144 KiB of LDS: 32-KiB stages, 4-deep ring (three stages ahead), 4 pieces and 24 (48) MFMAs per wave and
+//       stage, 20-KiB slabs: x 6, x1..x4 3 each (layer L: 3 + 3L stages, layer 5: 18) -- does the latency a 2.4-GHz clock exposes go away?
+template <int DEEP>
+struct Geo {
+    static constexpr int STAGE = DEEP ? 32 * 1024 : 48 * 1024, RING = DEEP ? 4 : 3, LOOK = RING - 1, PW = DEEP ? 4 : 6;
+    static constexpr int SLAB = DEEP ? 20 * 1024 : 32 * 1024, OWN = DEEP ? 20 : 32;           // KiB of the own slab per stage
+    static constexpr int XS = DEEP ? 6 : 4, GS = DEEP ? 3 : 2;                                  // slabs of x, of a growth plane
+    static constexpr int SLABS = 2 * XS + 4 * GS;
+    static constexpr int STEPS = DEEP ? 8 : 12;                                                  // light stage; heavy: twice
+};
 constexpr uint32_t kMaxSpin = 200000;
 
 __device__ __forceinline__ void mfma(f32x16& acc, const f16x8& a, const f16x8& b) {
@@ -59,9 +69,10 @@ __device__ __forceinline__ uint32_t poll(const uint32_t* p) {        // scalar, 
 }
 
 // the flattened sequence of stages of one workgroup: RDB r, layer L (1..5), patch p, stage st
+template <class G>
 struct Cursor {
     int r, L, p, st;
-    __device__ __forceinline__ int ns() const { return L < 5 ? 2 + 2 * L : 12; }
+    __device__ __forceinline__ int ns() const { return G::XS + G::GS * (L - 1); }              // layer 5 reads x and all four growth planes
     __device__ __forceinline__ bool last_of_patch() const { return st + 1 == ns(); }
     __device__ __forceinline__ void next(int P) {
         if (++st < ns()) return;
@@ -73,19 +84,23 @@ struct Cursor {
         ++r;
     }
     // which slab the stage reads, and the layer count its plane needs (0: the input, always there)
-    __device__ __forceinline__ int slab() const { return st < 4 ? ((r & 1) ? 4 : 0) + st : 8 + (st - 4); }
-    __device__ __forceinline__ uint32_t needs() const { return st < 4 ? 5u * (uint32_t)r : 5u * (uint32_t)r + (uint32_t)((st - 4) / 2 + 1); }
+    __device__ __forceinline__ int slab() const { return st < G::XS ? ((r & 1) ? G::XS : 0) + st : 2 * G::XS + (st - G::XS); }
+    __device__ __forceinline__ uint32_t needs() const {
+        return st < G::XS ? 5u * (uint32_t)r : 5u * (uint32_t)r + (uint32_t)((st - G::XS) / G::GS + 1);
+    }
 };
 
-template <int COH>
+template <int COH, int DEEP>
 __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restrict__ wts, uint32_t wchunks, char* __restrict__ ws, uint32_t* flags,
                                                              float* __restrict__ sink, int P, int rdbs, uint32_t* timeouts) {
+    using G = Geo<DEEP>;
+    constexpr int STAGE = G::STAGE, RING = G::RING, LOOK = G::LOOK, PW = G::PW, SLAB = G::SLAB;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int w = blockIdx.x, nwg = gridDim.x;
     const size_t nq = (size_t)nwg * P;
     {
-        const uint4* s4 = (const uint4*)(wts + (size_t)(w % wchunks) * STAGE);
+        const uint4* s4 = (const uint4*)(wts + (size_t)(w % wchunks) * (48 * 1024));
         for (int i = threadIdx.x; i < RING * STAGE / 16; i += 512) ((uint4*)smem)[i] = s4[i % (STAGE / 16)];
     }
     __syncthreads();
@@ -124,84 +139,93 @@ __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restr
             __builtin_amdgcn_s_sleep(4);
         }
     };
-    // LDS-DMA of one stage: this wave's six pieces into ring slot `slot`
-    auto dma = [&](const Cursor& c, int slot, int piece_i) {
+    // LDS-DMA of one stage: this wave's PW pieces into ring slot `slot` -- three quarters of the stage streamed (own slab + halo), a quarter weights
+    auto dma = [&](const Cursor<G>& c, int slot, int piece_i) {
         const uint32_t lds = (uint32_t)slot * STAGE + (uint32_t)(wave * PW + piece_i) * 1024;
-        if (piece_i < 4) {                                      // the patch's own slab: 8 waves x 4 KiB
-            glds16<COH>(slab_ptr(c.slab(), w, c.p) + (size_t)(wave * 4 + piece_i) * 1024, lane_off, lds, true);
-        } else if (piece_i == 5 && (wave & 1) == 0) {           // halo: 4 KiB of a neighbour workgroup's slab
-            glds16<COH>(slab_ptr(c.slab(), wave < 4 ? wl : wr, c.p) + (size_t)(wave * 2) * 1024, lane_off, lds, true);
-        } else {                                                // weights: 12 KiB from the cached buffer, the same for every workgroup
-            const uint32_t chunk = (uint32_t)(c.L * 12 + c.st) % wchunks;
-            glds16<COH>(wts + (size_t)chunk * STAGE + (size_t)(wave * PW + piece_i) * 1024, lane_off, lds, false);
+        int kind, off;                                          // 0 own slab (KiB offset), 1 halo, 2 weights
+        if (!DEEP) {                                            // 48 KiB: own 32 (4 per wave), halo 4 (even waves' last piece), weights 12
+            kind = piece_i < 4 ? 0 : (piece_i == 5 && (wave & 1) == 0) ? 1 : 2;
+            off = wave * 4 + piece_i;
+        } else {                                                // 32 KiB: own 20 (2 per wave + waves 0-3 a third), halo 4 (waves 4-7), weights 8
+            kind = piece_i < 2 ? 0 : piece_i == 2 ? (wave < 4 ? 0 : 1) : 2;
+            off = piece_i < 2 ? wave * 2 + piece_i : 16 + wave;
+        }
+        if (kind == 0) glds16<COH>(slab_ptr(c.slab(), w, c.p) + (size_t)off * 1024, lane_off, lds, true);
+        else if (kind == 1) glds16<COH>(slab_ptr(c.slab(), (wave & 2) ? wr : wl, c.p) + (size_t)(wave * 2) * 1024, lane_off, lds, true);
+        else {
+            const uint32_t chunk = (uint32_t)(c.L * 18 + c.st) % wchunks;
+            glds16<COH>(wts + (size_t)chunk * (48 * 1024) + (size_t)(wave * PW + piece_i) * 1024, lane_off, lds, false);
         }
     };
 
-    Cursor cur{0, 1, 0, 0}, ahead{0, 1, 0, 0};                  // `ahead`: the stage whose DMA is issued next (two ahead of `cur`)
+    Cursor<G> cur{0, 1, 0, 0}, ahead{0, 1, 0, 0};               // `ahead`: the stage whose DMA is issued next (LOOK ahead of `cur`)
     long total = 0;
-    for (int L = 1; L <= 5; ++L) total += (long)(L < 5 ? 2 + 2 * L : 12) * P;
+    for (int L = 1; L <= 5; ++L) total += (long)(G::XS + G::GS * (L - 1)) * P;
     total *= rdbs;
-    // prologue: stages 0 and 1
-    for (int k = 0; k < 2 && k < total; ++k) {
+    for (int k = 0; k < LOOK && k < total; ++k) {               // prologue: the first LOOK stages
         acquire(ahead.p, ahead.needs());
 #pragma unroll
         for (int i = 0; i < PW; ++i) dma(ahead, k % RING, i);
         ahead.next(P);
     }
-    int e_age = 0, e_cnt = 0;                                   // epilogue stores in flight: counted in the next two tops
+    int e_age = 0, e_cnt = 0;                                   // epilogue stores in flight: counted in the next LOOK tops
     int pub_p = -1;
     uint32_t pub_val = 0;
     for (long s = 0; s < total; ++s) {
         const uint32_t slot = (uint32_t)(s % RING) * STAGE;
-        // my pieces of stage s have landed; stores of a patch that ended one or two stages ago may stay in flight
-        if (e_age > 0 && e_cnt == 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW + 16) : "memory");
-        else if (e_age > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW + 8) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW) : "memory");
+        // my pieces of stage s have landed (younger: the pieces of the LOOK - 1 stages behind it, and the stores of a patch that ended within the
+        // last LOOK stages, which were issued behind those pieces)
+        if (e_age > 0 && e_cnt == 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (LOOK - 1) + 16) : "memory");
+        else if (e_age > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (LOOK - 1) + 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PW * (LOOK - 1)) : "memory");
         if (e_age > 0) --e_age;
         else if (pub_p >= 0) {
-            // two stages behind the stores: every wave's have completed (its wait above, then the barrier) -- publish the patch's counter
+            // LOOK stages behind the stores: every wave's have completed (its wait above, then the barrier) -- publish the patch's counter
             if (wave == 0 && lane == 0) __hip_atomic_store(flags + (size_t)w * P + pub_p, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub_p = -1;
         }
-        const bool have_ahead = s + 2 < total;
+        const bool have_ahead = s + LOOK < total;
         if (have_ahead) acquire(ahead.p, ahead.needs());
         const bool heavy = cur.L == 5;
-        auto body = [&](auto nsteps_c) __attribute__((always_inline)) {
-            constexpr int NSTEPS = decltype(nsteps_c)::value;
-            constexpr bool HEAVY = NSTEPS == 24;
+        auto body = [&](auto heavy_c) __attribute__((always_inline)) {
+            constexpr bool HEAVY = decltype(heavy_c)::value;
+            constexpr int NSTEPS = HEAVY ? 2 * G::STEPS : G::STEPS;
             int rd = 0;
 #pragma unroll
             for (int st = 0; st < NSTEPS; ++st) {
                 f16x8 na0 = a0, na1 = a1, nb = b;
                 auto piece = [&](int k) { return slot + (((uint32_t)wave * PW + (uint32_t)k) % (STAGE / 1024)) * 1024 + lane_off; };
-                nb = lds16(smem, piece(rd++));
+                nb = lds16(smem, piece(rd++));                  // 0.75 LDS reads per MFMA (heavy: 0.44: an A fragment serves both output-channel tiles)
                 if (HEAVY) {
                     if (st % 3 == 2) na0 = lds16(smem, piece(rd++));
                 } else {
                     na0 = lds16(smem, piece(rd++));
                     if (st % 4 == 3) na1 = lds16(smem, piece(rd++));
                 }
-                if (st < PW) { if (have_ahead) dma(ahead, (int)((s + 2) % RING), st); }
+                if (st < PW) { if (have_ahead) dma(ahead, (int)((s + LOOK) % RING), st); }
                 mfma(acc[(3 * st + 0) & 3], a0, b);
                 mfma(acc[(3 * st + 1) & 3], a1, b);
                 mfma(acc[(3 * st + 2) & 3], a2, b);
                 a0 = na0; a1 = na1; b = nb;
             }
         };
-        if (heavy) body(std::integral_constant<int, 24>{});
-        else body(std::integral_constant<int, 12>{});
+        if (heavy) body(std::true_type{});
+        else body(std::false_type{});
         if (have_ahead) ahead.next(P);
         if (cur.last_of_patch()) {
-            // the layer's output planes of this patch: x_L (2 slabs) or, layer 5, the other x (4 slabs); 1 KiB per store and wave
+            // the layer's output planes of this patch: x_L (64 KiB) or, layer 5, the other x (128 KiB); 1 KiB per store and wave
             const int nst = heavy ? 16 : 8;
-            const int first = heavy ? (((cur.r + 1) & 1) ? 4 : 0) : 8 + 2 * (cur.L - 1);
+            const int first = heavy ? (((cur.r + 1) & 1) ? G::XS : 0) : 2 * G::XS + G::GS * (cur.L - 1);
             const f32x4 v4 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
             for (int k = 0; k < nst; ++k) {
-                char* q = slab_ptr(first + (wave * nst + k) / 32, w, cur.p) + (size_t)((wave * nst + k) % 32) * 1024 + lane_off;
+                const int j = wave * nst + k;
+                int sl = first + j / (SLAB / 1024);
+                if (sl >= G::SLABS) sl = G::SLABS - 1;             // (G1: 64 KiB into 3 slabs of 20: the last 4 KiB stay inside the patch's planes)
+                char* q = slab_ptr(sl, w, cur.p) + (size_t)(j % (SLAB / 1024)) * 1024 + lane_off;
                 if (COH) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q), "v"(v4) : "memory");
                 else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(q), "v"(v4) : "memory");
             }
-            e_age = 2;
+            e_age = LOOK;
             e_cnt = nst;
             pub_p = cur.p;
             pub_val = 5u * (uint32_t)cur.r + (uint32_t)cur.L;
@@ -221,31 +245,35 @@ __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restr
 
 namespace s2sr {
 
-// wts: >= 160 chunks of 48 KiB (cached operand / weight data); ws: 16 slabs x grid x P x 32 KiB; flags: grid x P + 1 words of UNCACHED device
-// memory, zeroed by the caller before every launch; sink: grid x 512 floats; timeouts: one word (zeroed by the caller).
-hipError_t launch_rdb_persistent(int coherent, const char* d_wts, size_t wts_bytes, char* d_ws, uint32_t* d_flags, float* d_sink, int grid, int P,
+// variant: bit 0 = device-scope plane loads + written-through plane stores, bit 1 = the deeper geometry (G1).
+// wts: >= 8 chunks of 48 KiB (cached operand / weight data); ws: rdb_persistent_ws_bytes; flags: grid x P + 1 words of UNCACHED device memory,
+// zeroed by the caller before every launch; sink: grid x 512 floats; timeouts: one word (zeroed by the caller).
+hipError_t launch_rdb_persistent(int variant, const char* d_wts, size_t wts_bytes, char* d_ws, uint32_t* d_flags, float* d_sink, int grid, int P,
                                  int rdbs, uint32_t* d_timeouts, hipStream_t st) {
-    if (grid <= 0 || P < 1 || P > 4 || rdbs < 1 || wts_bytes < (size_t)STAGE * 8) return hipErrorInvalidValue;
-    const size_t lds = (size_t)RING * STAGE;
+    if (variant < 0 || variant > 3 || grid <= 0 || P < 2 || P > 4 || rdbs < 1 || wts_bytes < (size_t)48 * 1024 * 8) return hipErrorInvalidValue;
+    typedef void (*K)(const char*, uint32_t, char*, uint32_t*, float*, int, int, uint32_t*);
+    static const K kern[4] = {rdb_persistent_kernel<0, 0>, rdb_persistent_kernel<1, 0>, rdb_persistent_kernel<0, 1>, rdb_persistent_kernel<1, 1>};
+    static const size_t lds[4] = {(size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<1>::RING * Geo<1>::STAGE,
+                                  (size_t)Geo<1>::RING * Geo<1>::STAGE};
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute((const void*)rdb_persistent_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr_err == hipSuccess)
-            attr_err = hipFuncSetAttribute((const void*)rdb_persistent_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int v = 0; v < 4 && attr_err == hipSuccess; ++v)
+            attr_err = hipFuncSetAttribute((const void*)kern[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[v]);
     });
     if (attr_err != hipSuccess) return attr_err;
-    uint32_t wchunks = (uint32_t)(wts_bytes / STAGE);
+    uint32_t wchunks = (uint32_t)(wts_bytes / (48 * 1024));
     if (wchunks > 160) wchunks = 160;
-    if (coherent) hipLaunchKernelGGL(rdb_persistent_kernel<1>, dim3(grid), dim3(512), lds, st, d_wts, wchunks, d_ws, d_flags, d_sink, P, rdbs, d_timeouts);
-    else hipLaunchKernelGGL(rdb_persistent_kernel<0>, dim3(grid), dim3(512), lds, st, d_wts, wchunks, d_ws, d_flags, d_sink, P, rdbs, d_timeouts);
+    hipLaunchKernelGGL(kern[variant], dim3(grid), dim3(512), lds[variant], st, d_wts, wchunks, d_ws, d_flags, d_sink, P, rdbs, d_timeouts);
     return hipGetLastError();
 }
 
-size_t rdb_persistent_ws_bytes(int grid, int P) { return (size_t)kSlabsPerPatch * grid * P * SLAB; }
+size_t rdb_persistent_ws_bytes(int variant, int grid, int P) {
+    return (variant & 2) ? (size_t)Geo<1>::SLABS * grid * P * Geo<1>::SLAB : (size_t)Geo<0>::SLABS * grid * P * Geo<0>::SLAB;
+}
 double rdb_persistent_flop_per_launch(int grid, int P, int rdbs) {
-    // per patch and RDB: layers 1-4: 4 + 6 + 8 + 10 = 28 stages of 288 MFMAs, layer 5: 12 stages of 576
-    return (double)grid * P * rdbs * (28.0 * 288.0 + 12.0 * 576.0) * 32768.0;
+    // per patch and RDB, either geometry: layers 1-4 8064 MFMAs (28 stages of 288 / 42 of 192), layer 5 6912 (12 of 576 / 18 of 384)
+    return (double)grid * P * rdbs * (8064.0 + 6912.0) * 32768.0;
 }
 
 }  // namespace s2sr

@@ -293,9 +293,9 @@ double mfma_ceiling_flop_per_launch(int mode, int grid, int stages);
 double mfma_ceiling_dma_bytes_per_launch(int mode, int grid, int stages);
 
 // diagnostic prototype (persist.hip): an RDB-shaped loop whose workgroups stay across layers, planes handed over through flags
-hipError_t launch_rdb_persistent(int coherent, const char* d_wts, size_t wts_bytes, char* d_ws, uint32_t* d_flags, float* d_sink, int grid, int P,
+hipError_t launch_rdb_persistent(int variant, const char* d_wts, size_t wts_bytes, char* d_ws, uint32_t* d_flags, float* d_sink, int grid, int P,
                                  int rdbs, uint32_t* d_timeouts, hipStream_t st);
-size_t rdb_persistent_ws_bytes(int grid, int P);
+size_t rdb_persistent_ws_bytes(int variant, int grid, int P);
 double rdb_persistent_flop_per_launch(int grid, int P, int rdbs);
 
 }  // namespace s2sr

@@ -602,12 +602,13 @@ class Engine:
                 "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
                 "dma_GB_per_s": by.value * launches / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0}
 
-    def rdb_persistent(self, coherent: bool, grid: int, P: int, rdbs: int, launches: int) -> dict:
-        """csrc/persist.hip (diagnostic prototype): the RDB-shaped loop whose workgroups stay across layers -> TFLOP/s, dependency-wait timeouts."""
+    def rdb_persistent(self, variant: int, grid: int, P: int, rdbs: int, launches: int) -> dict:
+        """csrc/persist.hip (diagnostic prototype): the RDB-shaped loop whose workgroups stay across layers -> TFLOP/s, dependency-wait timeouts.
+        variant: bit 0 device-scope plane loads + written-through stores, bit 1 the deeper ring (32-KiB stages, three stages of look-ahead)."""
         fl, ms, to = C.c_double(0), C.c_float(0), C.c_int32(0)
-        self._check(self._lib.s2sr_debug_rdb_persistent(self._h, int(bool(coherent)), grid, P, rdbs, launches, C.byref(fl), C.byref(ms), C.byref(to)),
+        self._check(self._lib.s2sr_debug_rdb_persistent(self._h, int(variant), grid, P, rdbs, launches, C.byref(fl), C.byref(ms), C.byref(to)),
                     "s2sr_debug_rdb_persistent")
-        return {"ms": float(ms.value), "launches": launches, "timeouts": int(to.value), "working_set_MB": grid * P * 0.5,
+        return {"ms": float(ms.value), "launches": launches, "timeouts": int(to.value), "working_set_MB": grid * P * (0.46875 if int(variant) & 2 else 0.5),
                 "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
 
     # -- measurement ------------------------------------------------------------------------

@@ -1222,13 +1222,13 @@ def test_rdb_persistent_prototype_drains():
     e = native.Engine(num_block=1)
     try:
         ncu = torch.cuda.get_device_properties(0).multi_processor_count
-        for coherent in (0, 1):
+        for variant in (0, 1, 2, 3):      # bit 0: device-scope loads / written-through stores, bit 1: the deeper ring
             for grid, P in ((ncu, 2), (ncu // 2, 3), (8, 4)):
-                r = e.rdb_persistent(coherent, grid, P, 3, 2)
-                assert r["timeouts"] == 0 and r["ms"] > 0, (coherent, grid, P, r)
+                r = e.rdb_persistent(variant, grid, P, 3, 2)
+                assert r["timeouts"] == 0 and r["ms"] > 0, (variant, grid, P, r)
                 flop = r["TFLOP_per_s"] * 1e12 * r["ms"] * 1e-3 / 2
                 assert abs(flop - grid * P * 3 * (28 * 288 + 12 * 576) * 32768.0) < 1e-6 * flop, (grid, P, flop)
-        for bad in ((0, ncu + 1, 2, 3, 1), (0, ncu, 1, 3, 1), (0, ncu, 5, 3, 1), (0, ncu, 2, 0, 1)):
+        for bad in ((0, ncu + 1, 2, 3, 1), (0, ncu, 1, 3, 1), (0, ncu, 5, 3, 1), (0, ncu, 2, 0, 1), (4, ncu, 2, 3, 1)):
             with pytest.raises(native.S2srError):
                 e.rdb_persistent(*bad)
     finally:
