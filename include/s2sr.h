@@ -384,9 +384,11 @@ int  s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32
  * (at most one per CU, on an otherwise idle device: they must all be resident) of `P` = 2..4 patches each run `rdbs` RDB-shaped rounds per launch
  * (per patch 28 stages of 288 MFMAs + 12 of 576, 48 KiB of LDS-DMA per stage, the layer's planes stored behind each patch; working set
  * grid x P x 512 KiB); variant bit 0: plane loads with sc1, plane stores with sc0 sc1; bit 1: the same work on 32-KiB stages in a 4-deep ring
- * (three stages of look-ahead instead of two).  *timeouts: dependency waits that ran into their bound (must be 0 for the timing to mean anything). */
+ * (three stages of look-ahead instead of two); variant 4 / 5: variant 0 / 1 with the hand-over CHECKED -- the plane stores carry (layer count,
+ * writer) and every landed piece is compared: mismatches[0] = halo pieces (written by a workgroup on another XCD), mismatches[1] = own pieces.
+ * *timeouts: dependency waits that ran into their bound (must be 0 for the timing to mean anything). */
 int  s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t variant, int32_t grid, int32_t P, int32_t rdbs, int32_t launches, double* flop_per_launch,
-                               float* ms_total, int32_t* timeouts);
+                               float* ms_total, int32_t* timeouts, int32_t* mismatches);
 
 #ifdef __cplusplus
 }

@@ -2395,8 +2395,8 @@ int s2sr_debug_mfma_ceiling(s2sr_handle* h, int32_t mode, int32_t stages, int32_
 // diagnostic prototype (persist.hip): `launches` launches of the RDB-shaped loop whose workgroups stay across layers, `grid` workgroups (<= one per
 // CU: they must all be resident) of `P` patches each, `rdbs` RDBs per launch; flags in uncached device memory, zeroed in front of every launch
 int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t variant, int32_t grid, int32_t P, int32_t rdbs, int32_t launches, double* flop_per_launch,
-                              float* ms_total, int32_t* timeouts) {
-    if (!h || variant < 0 || variant > 3 || grid < 2 || P < 2 || P > 4 || rdbs < 1 || rdbs > 4000 || launches < 1 || !ms_total) return S2SR_E_INVALID;
+                              float* ms_total, int32_t* timeouts, int32_t* mismatches) {
+    if (!h || variant < 0 || variant > 5 || grid < 2 || P < 2 || P > 4 || rdbs < 1 || rdbs > 4000 || launches < 1 || !ms_total) return S2SR_E_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     int ncu = 256;
@@ -2418,7 +2418,7 @@ int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t variant, int32_t grid, int
     // operand data: the ceiling loops' generator fills the weights buffer and the working set (toggle rates as there)
     HIPCHK(h, launch_mfma_ceiling(0, (char*)h->d_scratch[2], wts_bytes, true, (float*)h->d_scratch[3], 1, 1, nullptr, 0, st));
     HIPCHK(h, launch_mfma_ceiling(0, (char*)h->d_scratch[4], ws_bytes, true, (float*)h->d_scratch[3], 1, 1, nullptr, 0, st));
-    HIPCHK(h, hipMemsetAsync(d_timeouts, 0, 4, st));
+    HIPCHK(h, hipMemsetAsync(d_timeouts, 0, 12, st));
     hipEvent_t e0 = get_event(h), e1 = get_event(h);
     auto one = [&]() -> int {
         HIPCHK(h, hipMemsetAsync(fl.p, 0, flag_bytes, st));
@@ -2432,13 +2432,14 @@ int s2sr_debug_rdb_persistent(s2sr_handle* h, int32_t variant, int32_t grid, int
     for (int i = 0; i < launches; ++i)
         if ((rc = one())) return rc;
     HIPCHK(h, hipEventRecord(e1, st));
-    uint32_t to = 0;
-    HIPCHK(h, hipMemcpyAsync(&to, d_timeouts, 4, hipMemcpyDeviceToHost, st));
+    uint32_t to[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(to, d_timeouts, 12, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
     h->ev_pool.push_back(e0); h->ev_pool.push_back(e1);
     if (flop_per_launch) *flop_per_launch = rdb_persistent_flop_per_launch(grid, P, rdbs);
-    if (timeouts) *timeouts = (int32_t)to;
+    if (timeouts) *timeouts = (int32_t)to[0];
+    if (mismatches) { mismatches[0] = (int32_t)to[1]; mismatches[1] = (int32_t)to[2]; }
     return S2SR_OK;
 }
 

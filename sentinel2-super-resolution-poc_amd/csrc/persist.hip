@@ -90,7 +90,7 @@ struct Cursor {
     }
 };
 
-template <int COH, int DEEP>
+template <int COH, int DEEP, int CHECK = 0>
 __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restrict__ wts, uint32_t wchunks, char* __restrict__ ws, uint32_t* flags,
                                                              float* __restrict__ sink, int P, int rdbs, uint32_t* timeouts) {
     using G = Geo<DEEP>;
@@ -184,6 +184,15 @@ __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restr
             if (wave == 0 && lane == 0) __hip_atomic_store(flags + (size_t)w * P + pub_p, pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub_p = -1;
         }
+        if (CHECK && !DEEP && cur.needs() != 0 && (wave & 1) == 0) {
+            // CHECK: the plane stores carry (layer count << 12 | writer); the halo piece of this stage, written by the neighbour workgroup (another
+            // XCD: workgroups go round the XCDs) and landed in LDS just now, must carry the count this stage waited for -- and so must the own slab
+            const uint32_t got_h = *(const uint32_t*)(smem + slot + (uint32_t)(wave * PW + 5) * 1024 + lane_off);
+            const uint32_t got_o = *(const uint32_t*)(smem + slot + (uint32_t)(wave * PW) * 1024 + lane_off);
+            const uint32_t wn = (uint32_t)((wave & 2) ? wr : wl);
+            if (got_h != ((cur.needs() << 12) | wn)) atomicAdd(timeouts + 1, 1u);
+            if (got_o != ((cur.needs() << 12) | (uint32_t)w)) atomicAdd(timeouts + 2, 1u);
+        }
         const bool have_ahead = s + LOOK < total;
         if (have_ahead) acquire(ahead.p, ahead.needs());
         const bool heavy = cur.L == 5;
@@ -216,7 +225,11 @@ __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restr
             // the layer's output planes of this patch: x_L (64 KiB) or, layer 5, the other x (128 KiB); 1 KiB per store and wave
             const int nst = heavy ? 16 : 8;
             const int first = heavy ? (((cur.r + 1) & 1) ? G::XS : 0) : 2 * G::XS + G::GS * (cur.L - 1);
-            const f32x4 v4 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+            f32x4 v4 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+            if (CHECK) {
+                const float tag = __builtin_bit_cast(float, ((5u * (uint32_t)cur.r + (uint32_t)cur.L) << 12) | (uint32_t)w);
+                v4 = (f32x4){tag, tag, tag, tag};
+            }
             for (int k = 0; k < nst; ++k) {
                 const int j = wave * nst + k;
                 int sl = first + j / (SLAB / 1024);
@@ -245,20 +258,22 @@ __global__ void __launch_bounds__(512) rdb_persistent_kernel(const char* __restr
 
 namespace s2sr {
 
-// variant: bit 0 = device-scope plane loads + written-through plane stores, bit 1 = the deeper geometry (G1).
+// variant: bit 0 = device-scope plane loads + written-through plane stores, bit 1 = the deeper geometry (G1); 4 / 5 = variant 0 / 1 with the
+// hand-over CHECKED: plane stores carry (layer count, writer), every landed halo piece and own piece is compared (timeouts[1], [2] = mismatches).
 // wts: >= 8 chunks of 48 KiB (cached operand / weight data); ws: rdb_persistent_ws_bytes; flags: grid x P + 1 words of UNCACHED device memory,
-// zeroed by the caller before every launch; sink: grid x 512 floats; timeouts: one word (zeroed by the caller).
+// zeroed by the caller before every launch; sink: grid x 512 floats; timeouts: three words (zeroed by the caller).
 hipError_t launch_rdb_persistent(int variant, const char* d_wts, size_t wts_bytes, char* d_ws, uint32_t* d_flags, float* d_sink, int grid, int P,
                                  int rdbs, uint32_t* d_timeouts, hipStream_t st) {
-    if (variant < 0 || variant > 3 || grid <= 0 || P < 2 || P > 4 || rdbs < 1 || wts_bytes < (size_t)48 * 1024 * 8) return hipErrorInvalidValue;
+    if (variant < 0 || variant > 5 || grid <= 0 || P < 2 || P > 4 || rdbs < 1 || wts_bytes < (size_t)48 * 1024 * 8) return hipErrorInvalidValue;
     typedef void (*K)(const char*, uint32_t, char*, uint32_t*, float*, int, int, uint32_t*);
-    static const K kern[4] = {rdb_persistent_kernel<0, 0>, rdb_persistent_kernel<1, 0>, rdb_persistent_kernel<0, 1>, rdb_persistent_kernel<1, 1>};
-    static const size_t lds[4] = {(size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<1>::RING * Geo<1>::STAGE,
-                                  (size_t)Geo<1>::RING * Geo<1>::STAGE};
+    static const K kern[6] = {rdb_persistent_kernel<0, 0>, rdb_persistent_kernel<1, 0>, rdb_persistent_kernel<0, 1>, rdb_persistent_kernel<1, 1>,
+                              rdb_persistent_kernel<0, 0, 1>, rdb_persistent_kernel<1, 0, 1>};
+    static const size_t lds[6] = {(size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<1>::RING * Geo<1>::STAGE,
+                                  (size_t)Geo<1>::RING * Geo<1>::STAGE, (size_t)Geo<0>::RING * Geo<0>::STAGE, (size_t)Geo<0>::RING * Geo<0>::STAGE};
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
-        for (int v = 0; v < 4 && attr_err == hipSuccess; ++v)
+        for (int v = 0; v < 6 && attr_err == hipSuccess; ++v)
             attr_err = hipFuncSetAttribute((const void*)kern[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[v]);
     });
     if (attr_err != hipSuccess) return attr_err;
@@ -269,7 +284,7 @@ hipError_t launch_rdb_persistent(int variant, const char* d_wts, size_t wts_byte
 }
 
 size_t rdb_persistent_ws_bytes(int variant, int grid, int P) {
-    return (variant & 2) ? (size_t)Geo<1>::SLABS * grid * P * Geo<1>::SLAB : (size_t)Geo<0>::SLABS * grid * P * Geo<0>::SLAB;
+    return (variant < 4 && (variant & 2)) ? (size_t)Geo<1>::SLABS * grid * P * Geo<1>::SLAB : (size_t)Geo<0>::SLABS * grid * P * Geo<0>::SLAB;
 }
 double rdb_persistent_flop_per_launch(int grid, int P, int rdbs) {
     // per patch and RDB, either geometry: layers 1-4 8064 MFMAs (28 stages of 288 / 42 of 192), layer 5 6912 (12 of 576 / 18 of 384)

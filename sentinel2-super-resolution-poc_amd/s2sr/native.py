@@ -138,7 +138,8 @@ _PROTOS = {
     "s2sr_debug_mfma_ceiling": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_float)]),
     "s2sr_debug_bench_conv": (C.c_int, [C.c_void_p] + [C.c_int32] * 6 + [C.POINTER(C.c_float), C.c_void_p, C.c_int32]),
-    "s2sr_debug_rdb_persistent": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "s2sr_debug_rdb_persistent": (C.c_int, [C.c_void_p] + [C.c_int32] * 5 + [C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
@@ -604,11 +605,12 @@ class Engine:
 
     def rdb_persistent(self, variant: int, grid: int, P: int, rdbs: int, launches: int) -> dict:
         """csrc/persist.hip (diagnostic prototype): the RDB-shaped loop whose workgroups stay across layers -> TFLOP/s, dependency-wait timeouts.
-        variant: bit 0 device-scope plane loads + written-through stores, bit 1 the deeper ring (32-KiB stages, three stages of look-ahead)."""
-        fl, ms, to = C.c_double(0), C.c_float(0), C.c_int32(0)
-        self._check(self._lib.s2sr_debug_rdb_persistent(self._h, int(variant), grid, P, rdbs, launches, C.byref(fl), C.byref(ms), C.byref(to)),
+        variant: bit 0 device-scope plane loads + written-through stores, bit 1 the deeper ring (32-KiB stages, three stages of look-ahead);
+        4 / 5: variant 0 / 1 with every handed-over piece checked (halo_mismatches, own_mismatches)."""
+        fl, ms, to, mm = C.c_double(0), C.c_float(0), C.c_int32(0), (C.c_int32 * 2)(0, 0)
+        self._check(self._lib.s2sr_debug_rdb_persistent(self._h, int(variant), grid, P, rdbs, launches, C.byref(fl), C.byref(ms), C.byref(to), mm),
                     "s2sr_debug_rdb_persistent")
-        return {"ms": float(ms.value), "launches": launches, "timeouts": int(to.value), "working_set_MB": grid * P * (0.46875 if int(variant) & 2 else 0.5),
+        return {"ms": float(ms.value), "launches": launches, "timeouts": int(to.value), "halo_mismatches": int(mm[0]), "own_mismatches": int(mm[1]), "working_set_MB": grid * P * (0.46875 if int(variant) & 2 else 0.5),
                 "TFLOP_per_s": fl.value * launches / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
 
     # -- measurement ------------------------------------------------------------------------
