@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Check of the cross-XCD hand-over of the persistent-loop prototype (csrc/persist.hip variants 4 / 5): the plane stores carry (layer count, writer)
+and every landed halo / own piece is compared -- plain loads and stores against device-scope loads and written-through stores
+(profiles/r05_persistent_loop.txt)."""
 import sys
 sys.path.insert(0, "sentinel2-super-resolution-poc_amd")
 from s2sr import native
